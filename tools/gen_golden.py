@@ -1,0 +1,519 @@
+"""Generate the golden fixtures under tests/golden/ from the reference implementation.
+
+Runs ONLY in the build container (needs /root/reference, CPU).  For every fixture
+it also cross-checks this repo's CPU oracle (oracle/*.py) against the reference
+output before writing, so a fixture is never written from a disagreeing pair.
+
+    python tools/gen_golden.py
+
+Fixtures are plain .npz files (numpy arrays only; loaded with allow_pickle=False).
+State dicts are stored with keys "sd/<state_dict key>".
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader  # noqa: E402
+from tests._weights import synthetic_state_dict  # noqa: E402
+
+ref = ref_loader.load()
+from oracle import denoiser as O_den, diffusion as O_dif, features as O_feat, heads as O_heads  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def npz(name, **arrays):
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = vv.detach().cpu().numpy() if torch.is_tensor(vv) else np.asarray(vv)
+        else:
+            flat[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def close(a, b, tol=1e-5, what=""):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    ref_mag = max(b.abs().max().item(), 1e-12)
+    assert err <= tol * max(ref_mag, 1.0), f"oracle != reference for {what}: {err} (mag {ref_mag})"
+
+
+def ragged_graph(bs, n, sizes, cx, ce, gen):
+    """Clean dense graphs in the reference's to_dense convention: padded nodes all-zero X,
+    every off-diagonal pair (padded ones too) has a one-hot E (class 0 = no bond), diagonal zero."""
+    mask = torch.arange(n)[None, :] < torch.tensor(sizes)[:, None]
+    Xc = torch.randint(0, cx, (bs, n), generator=gen)
+    X = F.one_hot(Xc, cx).float() * mask.unsqueeze(-1)
+    Ec = torch.randint(0, ce, (bs, n, n), generator=gen)
+    Ec = Ec * (torch.rand(bs, n, n, generator=gen) < 0.35)
+    Ec = torch.triu(Ec, 1)
+    Ec = Ec + Ec.transpose(1, 2)
+    pair = mask.unsqueeze(1) & mask.unsqueeze(2)
+    Ec = Ec * pair                                     # padded pairs: class 0
+    E = F.one_hot(Ec, ce).float()
+    E[:, torch.arange(n), torch.arange(n)] = 0
+    return X, E, mask
+
+
+# =============================================================================== G1/G2 schedule + transitions
+def gen_schedule():
+    T = 500
+    ns = ref.dnoise.PredefinedNoiseScheduleDiscrete(timesteps=T)
+    sch = O_dif.Schedule(T)
+    assert torch.equal(ns.betas, sch.betas) and torch.equal(ns.alphas_bar, sch.alphas_bar)
+    mx = torch.tensor([0.72, 0.12, 0.10, 0.04, 0.02])
+    me = torch.tensor([0.90, 0.05, 0.03, 0.01, 0.01])
+    tm = ref.dnoise.MarginalUniformTransition(mx, me, y_classes=4)
+    t_int = torch.tensor([[0.], [1.], [250.], [499.], [500.]])
+    beta = ns(t_normalized=t_int / T)
+    abar = ns.get_alpha_bar(t_normalized=t_int / T)
+    abar_s = ns.get_alpha_bar(t_normalized=(t_int - 1) / T)
+    qt, qtb = tm.get_Qt(beta, "cpu"), tm.get_Qt_bar(abar, "cpu")
+    assert torch.equal(qt.X, O_dif.Qt(beta, mx)) and torch.equal(qtb.E, O_dif.Qt_bar(abar, me))
+    npz("schedule", betas=ns.betas, alphas_bar=ns.alphas_bar, t_int=t_int, beta_t=beta, alpha_t_bar=abar,
+        alpha_s_bar=abar_s, mx=mx, me=me, Qt_X=qt.X, Qt_E=qt.E, Qtb_X=qtb.X, Qtb_E=qtb.E)
+
+
+# =============================================================================== G3/G4 noising
+class _NoiseHost(nn.Module):
+    """Just enough of FullDTIModel's attribute surface for apply_noise / get_extra_features."""
+
+
+def make_full_model(phase="pretrain_drug", cx=8, tiny=True, T=500, seed=0, n_dec_layers=2):
+    full = ref_loader.load_full()
+    torch.manual_seed(seed)
+    atom_types = ["C", "O", "P", "N", "S", "Cl", "F", "H"][:cx]
+    emb, hid = (32, 16) if tiny else (1024, 512)
+    gt_kwargs = dict(
+        n_layers=n_dec_layers,
+        input_dims={"X": cx + 8, "E": 5, "y": emb + 13},
+        output_dims={"X": cx, "E": 5, "y": emb},
+        hidden_mlp_dims={"X": 24, "E": 16, "y": 40} if tiny else {"X": 256, "E": 128, "y": 2048},
+        hidden_dims=({"dx": 32, "de": 16, "dy": 32, "n_head": 4, "dim_ffX": 24, "dim_ffE": 16, "dim_ffy": 40} if tiny else
+                     {"dx": 256, "de": 64, "dy": 1024, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 1024}),
+    )
+    nm = torch.tensor([0.55, 0.15, 0.02, 0.12, 0.05, 0.04, 0.05, 0.02][:cx]); nm = nm / nm.sum()
+    infos = {
+        "general": {"atom_types": atom_types, "bond_types": ["SINGLE", "DOUBLE", "TRIPLE", "AROMATIC"],
+                    "num_atom_types": cx, "max_n_nodes": 64,
+                    "atom_valencies": [4, 2, 3, 3, 2, 1, 1, 1][:cx],
+                    "atom_weights": [12.011, 15.999, 30.974, 14.007, 32.06, 35.45, 18.998, 1.008][:cx],
+                    "max_weight": 1000},
+        "dataset": {"dataset_name": "synthetic", "max_nodes": 64,
+                    "node_count_distribution": {"3": 1, "5": 2, "7": 3, "9": 2},
+                    "node_marginals": nm.tolist(),
+                    "edge_marginals": [0.90, 0.05, 0.03, 0.01, 0.01], "valency_distribution": []},
+    }
+    kw = dict(
+        phase=phase, finetune_score=None, learning_rate=5e-4, weight_decay=1e-4, scheduler="const",
+        weights=[1.0, 0.001, 0.5, 3.0], dti_weights=[1.0, 0.903964, 0.282992, 0.755172] if phase == "train" else None,
+        diff_weights=[1, 5], contrastive_temp=0.1,
+        drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 24} if tiny else {"FP-Morgan": 2048},
+        target_features={"FP-ESP": 48, "EMB-ESM": 40, "EMB-NT": 20} if phase == "train" else {},
+        embedding_dim=emb, hidden_dim=hid, factor=4, n_layers=2, activation="relu", dropout=0.1, bias=True,
+        encoder_type="transformer", aggregator_type="attentive", diffusion_steps=T, sample_every_val=5,
+        val_samples_per_embedding=2, test_samples_per_embedding=2, graph_transformer_kwargs=gt_kwargs, dataset_infos=infos)
+    model = full.FullDTIModel(**kw)
+    return model, kw, infos
+
+
+def gen_noise():
+    model, kw, infos = make_full_model()
+    cx, ce, bs, n = 8, 5, 4, 9
+    g = torch.Generator().manual_seed(11)
+    X, E, mask = ragged_graph(bs, n, [9, 7, 5, 3], cx, ce, g)
+    mx = torch.tensor(infos["dataset"]["node_marginals"]); me = torch.tensor(infos["dataset"]["edge_marginals"])
+    sch = O_dif.Schedule(500)
+
+    # --- G3: sample_discrete_features on arbitrary row-stochastic inputs
+    probX = torch.softmax(torch.randn(bs, n, cx, generator=g), -1)
+    probE = torch.softmax(torch.randn(bs, n, n, ce, generator=g), -1)
+    probE[0, 0, 1] = torch.tensor([0., 0.5, 0., 0.5, 0.])          # zero-probability classes
+    torch.manual_seed(123)
+    out = ref.dutils.sample_discrete_features(probX.clone(), probE.clone(), mask)
+    torch.manual_seed(123)
+    expX = torch.empty(bs * n, cx).exponential_(1)
+    expE = torch.empty(bs * n * n, ce).exponential_(1)
+    oX, oE = O_dif.sample_graph(probX, probE, mask, expX, expE)
+    assert torch.equal(out.X, oX) and torch.equal(out.E, oE), "sampler mismatch"
+    rec = dict(X=X, E=E, mask=mask, mx=mx, me=me, s_probX=probX, s_probE=probE, s_expX=expX, s_expE=expE,
+               s_X=out.X, s_E=out.E)
+
+    # --- G4: apply_noise, train (t may be 0) and eval (t >= 1)
+    for mode, seed in (("train", 5), ("eval", 6)):
+        model.train(mode == "train")
+        torch.manual_seed(seed)
+        X_t, E_t, npar = model.apply_noise(X.clone(), E.clone(), mask)
+        torch.manual_seed(seed)
+        low = 0 if mode == "train" else 1
+        t_int = torch.randint(low, 501, size=(bs, 1)).float()
+        eX = torch.empty(bs * n, cx).exponential_(1)
+        eE = torch.empty(bs * n * n, ce).exponential_(1)
+        assert torch.equal(t_int, npar["t_int"])
+        oXt, oEt, onp, Xc, Ec = O_dif.apply_noise(sch, mx, me, X, E, mask, t_int, eX, eE)
+        assert torch.equal(oXt, X_t.float()) and torch.equal(oEt, E_t.float())
+        for k in ("t", "beta_t", "alpha_s_bar", "alpha_t_bar"):
+            assert torch.equal(onp[k], npar[k]), k
+        rec.update({f"{mode}_t_int": t_int, f"{mode}_expX": eX, f"{mode}_expE": eE, f"{mode}_X_t": X_t.float(),
+                    f"{mode}_E_t": E_t.float(), f"{mode}_Xc": Xc, f"{mode}_Ec": Ec,
+                    **{f"{mode}_{k}": npar[k] for k in ("t", "beta_t", "alpha_s_bar", "alpha_t_bar")}})
+    # force t = 0 in one extra train-mode case (s = -1 wraps to alphas_bar[T])
+    t0 = torch.tensor([[0.], [500.], [1.], [2.]])
+    _, _, onp, _, _ = O_dif.apply_noise(sch, mx, me, X, E, mask, t0, eX, eE)
+    ns = model.noise_schedule
+    assert torch.equal(ns.get_alpha_bar(t_normalized=(t0 - 1) / 500), onp["alpha_s_bar"])
+    rec.update(t0_t_int=t0, t0_alpha_s_bar=onp["alpha_s_bar"], t0_beta_t=onp["beta_t"])
+
+    # --- limit-distribution sampling (sample_discrete_feature_noise)
+    lim = ref.dutils.PlaceHolder(X=mx, E=me, y=None)
+    torch.manual_seed(77)
+    zT = ref.dutils.sample_discrete_feature_noise(lim, mask)
+    torch.manual_seed(77)
+    eX = torch.empty(bs * n, cx).exponential_(1)
+    eE = torch.empty(bs * n * n, ce).exponential_(1)
+    lX, lE = O_dif.sample_limit(mx, me, mask, eX, eE)
+    assert torch.equal(lX, zT.X) and torch.equal(lE, zT.E)
+    rec.update(lim_expX=eX, lim_expE=eE, lim_X=zT.X, lim_E=zT.E)
+    npz("noise", **rec)
+    return model, infos, X, E, mask, rec
+
+
+# =============================================================================== G5 extra features
+def gen_features(model, infos, X, E, mask, rec):
+    X_t, E_t = rec["eval_X_t"], rec["eval_E_t"]
+    t = rec["eval_t"]
+    bs, n = mask.shape
+    torch.manual_seed(31)
+    Xe, ye = model.get_extra_features(X_t, E_t, {"t": t}, mask)
+    torch.manual_seed(31)
+    noise = torch.randn(bs, n)
+    gen_ = infos["general"]
+    oXe, oye = O_feat.extra_features(X_t, E_t, t, mask, noise, gen_["max_n_nodes"], gen_["atom_valencies"],
+                                     gen_["atom_weights"], gen_["max_weight"])
+    # eigenvector columns (4,5) are sign-gauge dependent; everything else must match
+    close(oXe[..., :4], Xe[..., :4], what="X_extra cycles/lcc")
+    close(oXe[..., 6:], Xe[..., 6:], what="X_extra charge/valency")
+    close(oXe[..., 4:6].abs(), Xe[..., 4:6].abs(), tol=1e-4, what="X_extra |eigvec|")
+    close(oye, ye, tol=1e-5, what="y_extra")
+    # a denser graph exercises the cycle formulas harder
+    g = torch.Generator().manual_seed(3)
+    Ad = (torch.rand(3, 12, 12, generator=g) < 0.4).float()
+    Ad = torch.triu(Ad, 1); Ad = Ad + Ad.transpose(1, 2)
+    kx, ky = ref.daug.KNodeCycles().k_cycles(Ad)
+    okx, oky = O_feat.cycle_features(Ad)
+    close(okx, kx, what="cycles x"); close(oky, ky, what="cycles y")
+    L = O_feat.laplacian_masked(E_t, mask)
+    w = torch.linalg.eigvalsh(L)
+    npz("features", X_t=X_t, E_t=E_t, t=t, mask=mask, lcc_noise=noise, X_extra=Xe, y_extra=ye,
+        dense_A=Ad, dense_kx=kx, dense_ky=ky, laplacian=L, eigvals=w,
+        valencies=torch.tensor(gen_["atom_valencies"]), atom_weights=torch.tensor(gen_["atom_weights"]),
+        max_weight=torch.tensor(gen_["max_weight"]), max_n_nodes=torch.tensor(gen_["max_n_nodes"]))
+
+
+# =============================================================================== G6/G7 denoiser
+def gen_denoiser():
+    torch.manual_seed(2)
+    dims = dict(n_layers=2, input_dims={"X": 13, "E": 5, "y": 45}, hidden_mlp_dims={"X": 24, "E": 16, "y": 40},
+                hidden_dims={"dx": 32, "de": 16, "dy": 32, "n_head": 4, "dim_ffX": 24, "dim_ffE": 16, "dim_ffy": 40},
+                output_dims={"X": 5, "E": 5, "y": 32})
+    net = ref.gt.GraphTransformer(act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), **dims).eval()
+    bs, n = 4, 9
+    g = torch.Generator().manual_seed(8)
+    mask = torch.arange(n)[None, :] < torch.tensor([9, 7, 5, 3])[:, None]
+    X = torch.randn(bs, n, 13, generator=g)
+    E = torch.randn(bs, n, n, 5, generator=g); E = (E + E.transpose(1, 2)) / 2
+    y = torch.randn(bs, 45, generator=g)
+    cX, cE, cy = (torch.randn(bs, n, 5, generator=g), torch.randn(bs, n, n, 5, generator=g), torch.randn(bs, 32, generator=g))
+    Xr, Er, yr = (t.clone().requires_grad_(True) for t in (X, E, y))
+    out = net(Xr, Er, yr, mask)
+    loss = (out.X * cX).sum() + (out.E * cE).sum() + (out.y * cy).sum()
+    loss.backward()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    # oracle check (fwd + autograd grads)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    Xo, Eo, yo = (t.clone().requires_grad_(True) for t in (X, E, y))
+    oX, oE, oy = O_den.graph_transformer(p, Xo, Eo, yo, mask, 2, 4, dims["output_dims"])
+    close(oX, out.X, what="denoiser X"); close(oE, out.E, what="denoiser E"); close(oy, out.y, what="denoiser y")
+    ((oX * cX).sum() + (oE * cE).sum() + (oy * cy).sum()).backward()
+    for k in grads:
+        close(p[k].grad, grads[k], tol=2e-5, what="grad " + k)
+    close(Xo.grad, Xr.grad, what="dX"); close(Eo.grad, Er.grad, what="dE"); close(yo.grad, yr.grad, what="dy")
+    npz("denoiser_tiny", sd=sd, grad=grads, X=X, E=E, y=y, mask=mask, cX=cX, cE=cE, cy=cy,
+        out_X=out.X, out_E=out.E, out_y=out.y, dX=Xr.grad, dE=Er.grad, dy=yr.grad, loss=loss.detach())
+
+    # ---- one layer + NodeEdgeBlock intermediates (hidden-width inputs, properly masked)
+    layer = net.tf_layers[0]
+    hX = torch.randn(bs, n, 32, generator=g) * mask.unsqueeze(-1)
+    hE = torch.randn(bs, n, n, 16, generator=g); hE = (hE + hE.transpose(1, 2)) / 2
+    hE = hE * (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1)
+    hy = torch.randn(bs, 32, generator=g)
+    cap = {}
+    blk = layer.self_attn
+    hooks = [getattr(blk, nm).register_forward_hook(lambda m, i, o, nm=nm: cap.__setitem__(nm, o.detach().clone()))
+             for nm in ("q", "k", "v", "e_mul", "e_add", "y_e_add", "y_e_mul", "y_x_add", "y_x_mul")]
+    hooks += [blk.e_out.register_forward_hook(lambda m, i, o: cap.__setitem__("e_out_in", i[0].detach().clone())),
+              blk.x_out.register_forward_hook(lambda m, i, o: cap.__setitem__("x_out_in", i[0].detach().clone())),
+              blk.x_y.register_forward_hook(lambda m, i, o: cap.__setitem__("x_y", o.detach().clone())),
+              blk.e_y.register_forward_hook(lambda m, i, o: cap.__setitem__("e_y", o.detach().clone()))]
+    with torch.no_grad():
+        nX, nE, ny = blk(hX, hE, hy, mask)
+        lX, lE, ly = layer(hX, hE, hy, mask)
+    for h in hooks:
+        h.remove()
+    lsd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        olX, olE, oly = O_den.xey_layer(lsd, hX, hE, hy, mask, 4)
+        xm = mask.unsqueeze(-1).float(); em = xm.unsqueeze(2) * xm.unsqueeze(1)
+        pre, wV = O_den.edge_attention(cap["q"] * xm, cap["k"] * xm, cap["v"] * xm, cap["e_mul"] * em, cap["e_add"] * em,
+                                       cap["y_e_add"], cap["y_e_mul"], mask, 4)
+    close(olX, lX, what="layer X"); close(olE, lE, what="layer E"); close(oly, ly, what="layer y")
+    close(pre, cap["e_out_in"], what="newE_pre")
+    close(cap["y_x_add"].unsqueeze(1) + (cap["y_x_mul"].unsqueeze(1) + 1) * wV, cap["x_out_in"], what="wV film")
+    # Xtoy / Etoy
+    close(O_den.pool_stats(hX, (1,)) @ lsd["self_attn.x_y.lin.weight"].T + lsd["self_attn.x_y.lin.bias"], cap["x_y"], what="Xtoy")
+    close(O_den.pool_stats(hE, (1, 2)) @ lsd["self_attn.e_y.lin.weight"].T + lsd["self_attn.e_y.lin.bias"], cap["e_y"], what="Etoy")
+    npz("layer_tiny", sd=lsd, X=hX, E=hE, y=hy, mask=mask, cap=cap, blk_X=nX, blk_E=nE, blk_y=ny,
+        out_X=lX, out_E=lE, out_y=ly, wV=wV)
+
+    # ---- one real-width single graph (dx=256,de=64,dy=1024,H=8), forward only, 1 layer
+    torch.manual_seed(4)
+    rdims = dict(n_layers=1, input_dims={"X": 13, "E": 5, "y": 1037}, hidden_mlp_dims={"X": 256, "E": 128, "y": 2048},
+                 hidden_dims={"dx": 256, "de": 64, "dy": 1024, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 1024},
+                 output_dims={"X": 5, "E": 5, "y": 1024})
+    rnet = ref.gt.GraphTransformer(act_fn_in=nn.ReLU(), act_fn_out=nn.ReLU(), **rdims).eval()
+    # weights too large to store: both sides rebuild them from tests/_weights.py (name-seeded)
+    rnet.load_state_dict(synthetic_state_dict({k: tuple(v.shape) for k, v in rnet.state_dict().items()}))
+    n2 = 6
+    m2 = torch.tensor([[True] * 5 + [False]])
+    X2 = torch.randn(1, n2, 13, generator=g); E2 = torch.randn(1, n2, n2, 5, generator=g); E2 = (E2 + E2.transpose(1, 2)) / 2
+    y2 = torch.randn(1, 1037, generator=g)
+    with torch.no_grad():
+        o2 = rnet(X2, E2, y2, m2)
+        q2 = O_den.graph_transformer(rnet.state_dict(), X2, E2, y2, m2, 1, 8, rdims["output_dims"])
+    close(q2[0], o2.X, what="real X"); close(q2[1], o2.E, what="real E"); close(q2[2], o2.y, tol=2e-5, what="real y")
+    shapes = {k: tuple(v.shape) for k, v in rnet.state_dict().items()}
+    npz("denoiser_realwidth", X=X2, E=E2, y=y2, mask=m2, out_X=o2.X, out_E=o2.E, out_y=o2.y,
+        shape_names=np.array(list(shapes.keys())), shape_dims=np.array([list(s) + [0] * (2 - len(s)) for s in shapes.values()]))
+
+
+# =============================================================================== G8-G10 heads / encoders
+def gen_heads():
+    g = torch.Generator().manual_seed(21)
+    rec = {}
+    bs, n, cx, ce = 4, 9, 8, 5
+    X, E, mask = ragged_graph(bs, n, [9, 7, 5, 3], cx, ce, g)
+    xm = mask.unsqueeze(-1).float(); em = xm.unsqueeze(2) * xm.unsqueeze(1)
+    pX = (torch.randn(bs, n, cx, generator=g) * xm).requires_grad_(True)
+    pE = torch.randn(bs, n, n, ce, generator=g); pE = ((pE + pE.transpose(1, 2)) / 2 * em).requires_grad_(True)
+    head = ref.heads.ReconstructionHead([1, 5])
+    loss = head(pX, pE, X, E)
+    loss.backward()
+    oX, oE = pX.detach().clone().requires_grad_(True), pE.detach().clone().requires_grad_(True)
+    ol = O_heads.reconstruction_loss(oX, oE, X, E, [1, 5]); ol.backward()
+    close(ol, loss, what="recon loss"); close(oX.grad, pX.grad, what="recon dX"); close(oE.grad, pE.grad, what="recon dE")
+    # per-class BCE trackers
+    full = ref_loader.load_full()
+    from mb_vae_dti.training.metrics.molecular_metrics import CEPerClass
+    bce_X = torch.stack([CEPerClass(c)(pX.detach(), X) for c in range(cx)])
+    bce_E = torch.stack([CEPerClass(c)(pE.detach(), E) for c in range(ce)])
+    tX, nX = O_heads.per_class_bce(pX.detach(), X); tE, nE = O_heads.per_class_bce(pE.detach(), E)
+    close(tX / nX, bce_X, what="bce X"); close(tE / nE, bce_E, what="bce E")
+    rec.update(rc_true_X=X, rc_true_E=E, rc_mask=mask, rc_pred_X=pX.detach(), rc_pred_E=pE.detach(), rc_loss=loss.detach(),
+               rc_dX=pX.grad, rc_dE=pE.grad, rc_bce_X=bce_X, rc_bce_E=bce_E)
+
+    # KL head
+    torch.manual_seed(3)
+    kl = ref.heads.KLVariationalHead(32, 32)
+    x = torch.randn(6, 32, generator=g)
+    torch.manual_seed(9); z, mu, lv = kl(x)
+    torch.manual_seed(9); eps = torch.randn_like(mu)
+    oz, omu, olv = O_heads.kl_head(kl.state_dict(), x, eps)
+    close(oz, z, what="kl z"); close(O_heads.kl_divergence(omu, olv), kl.kl_divergence(mu, lv), what="kl")
+    rec.update(kl_sd_w_mu=kl.fc_mu.weight, kl_sd_b_mu=kl.fc_mu.bias, kl_sd_w_lv=kl.fc_logvar.weight, kl_sd_b_lv=kl.fc_logvar.bias,
+               kl_x=x, kl_eps=eps, kl_z=z, kl_mu=mu, kl_logvar=lv, kl_value=kl.kl_divergence(mu, lv))
+    npz("heads", **rec)
+
+    # encoders, aggregators, fusion, DTI head, InfoNCE: state dicts + in/out (+ input grads)
+    torch.manual_seed(5)
+    mods = {
+        "resenc": ref.blocks.ResidualEncoder(40, 16, 24, n_layers=2, factor=4, dropout=0.1).eval(),
+        "trfenc": ref.blocks.TransformerEncoder(40, 16, 24, n_layers=2, factor=4, dropout=0.1).eval(),
+        "concat": ref.blocks.ConcatAggregator(16, 24, 3).eval(),
+        "attagg": ref.blocks.AttentiveAggregator(16, 24, 3).eval(),
+        "fusion": ref.blocks.CrossAttentionFusion(24, 16, n_layers=2, factor=4, dropout=0.1).eval(),
+        "dtihead": ref.heads.DTIHead(16, 8, 0.1, True, nn.ReLU()).eval(),
+        "infonce": ref.heads.InfoNCEHead(24, 8, 0.1, True, nn.ReLU()).eval(),
+    }
+    B = 6
+    enc = {}
+    xin = torch.randn(B, 40, generator=g)
+    feats = [torch.randn(B, 16, generator=g) for _ in range(3)]
+    a, b = torch.randn(B, 24, generator=g), torch.randn(B, 24, generator=g)
+    fp = (torch.rand(B, 64, generator=g) < 0.2).float()
+    h16 = torch.randn(B, 16, generator=g)
+    with torch.no_grad():
+        enc["resenc_out"] = mods["resenc"](xin); close(O_heads.residual_encoder(mods["resenc"].state_dict(), xin), enc["resenc_out"], what="resenc")
+        enc["trfenc_out"] = mods["trfenc"](xin); close(O_heads.transformer_encoder(mods["trfenc"].state_dict(), xin), enc["trfenc_out"], what="trfenc")
+        enc["concat_out"] = mods["concat"](feats); close(O_heads.concat_aggregator(mods["concat"].state_dict(), feats), enc["concat_out"], what="concat")
+        o, w = mods["attagg"](feats); enc["attagg_out"], enc["attagg_w"] = o, w
+        oo, ow = O_heads.attentive_aggregator(mods["attagg"].state_dict(), feats); close(oo, o, what="attagg"); close(ow, w, what="attagg w")
+        o, w = mods["fusion"](a, b); enc["fusion_out"], enc["fusion_w"] = o, w
+        oo, ow = O_heads.cross_attention_fusion(mods["fusion"].state_dict(), a, b); close(oo, o, what="fusion"); close(ow, w, what="fusion w")
+        d = mods["dtihead"](h16); od = O_heads.dti_head(mods["dtihead"].state_dict(), h16)
+        for k in d:
+            enc["dtihead_" + k] = d[k]; close(od[k], d[k], what="dti " + k)
+        enc["infonce_loss"] = mods["infonce"](a, fp, 0.1); close(O_heads.info_nce(mods["infonce"].state_dict(), a, fp, 0.1), enc["infonce_loss"], what="infonce")
+    targets = {"Y": (torch.rand(B, generator=g) < 0.3).float(), "Y_pKd": torch.randn(B, generator=g) + 6,
+               "Y_pKi": torch.randn(B, generator=g) + 6, "Y_KIBA": torch.randn(B, generator=g) + 11}
+    masks = {"Y_pKd": torch.tensor([1, 0, 1, 1, 0, 0]).bool(), "Y_pKi": torch.zeros(B).bool(), "Y_KIBA": torch.tensor([0, 1, 1, 0, 1, 1]).bool()}
+    acc, comps = O_heads.dti_accuracy_loss(d, targets, masks, [1.0, 0.903964, 0.282992, 0.755172])
+    enc.update(xin=xin, f0=feats[0], f1=feats[1], f2=feats[2], a=a, b=b, fp=fp, h16=h16)
+    npz("encoders", **enc, **{f"sd_{nm}": {k: v for k, v in m.state_dict().items()} for nm, m in mods.items()},
+        tgt=targets, msk=masks, dti_acc=acc)
+
+
+# =============================================================================== G11 posteriors / ELBO pieces
+def gen_posterior(model, infos, X, E, mask, rec):
+    mx = torch.tensor(infos["dataset"]["node_marginals"]); me = torch.tensor(infos["dataset"]["edge_marginals"])
+    sch = O_dif.Schedule(500)
+    bs, n = mask.shape
+    X_t, E_t = rec["eval_X_t"], rec["eval_E_t"]
+    noise = {k: rec["eval_" + k] for k in ("t", "beta_t", "alpha_s_bar", "alpha_t_bar")}
+    tm = model.transition_model
+    Qtb = tm.get_Qt_bar(noise["alpha_t_bar"], "cpu"); Qsb = tm.get_Qt_bar(noise["alpha_s_bar"], "cpu"); Qt_ = tm.get_Qt(noise["beta_t"], "cpu")
+    g = torch.Generator().manual_seed(14)
+    lX = torch.randn(bs, n, 8, generator=g); lE = torch.randn(bs, n, n, 5, generator=g); lE = (lE + lE.transpose(1, 2)) / 2
+    out = {}
+    pt = ref.dutils.compute_posterior_distribution(E, E_t, Qt_.E, Qsb.E, Qtb.E)
+    close(O_dif.posterior(E, E_t, O_dif.Qt(noise["beta_t"], me), O_dif.Qt_bar(noise["alpha_s_bar"], me), O_dif.Qt_bar(noise["alpha_t_bar"], me)), pt, what="posterior E")
+    out["post_true_E"] = pt
+    pb = ref.dutils.compute_batched_over0_posterior_distribution(X_t, Qt_.X, Qsb.X, Qtb.X)
+    close(O_dif.posterior_over_x0(X_t, O_dif.Qt(noise["beta_t"], mx), O_dif.Qt_bar(noise["alpha_s_bar"], mx), O_dif.Qt_bar(noise["alpha_t_bar"], mx)), pb, what="batched posterior X")
+    out["post_over0_X"] = pb
+    # kl_prior
+    dc = ref.dc
+    bd = dc.BatchData(graph_data=dc.GraphData(X=X, E=E, node_mask=mask, X_t=X_t, E_t=E_t, noise_params=noise))
+    klp = model.kl_prior(bd)
+    close(O_dif.kl_prior(sch, mx, me, X, E, mask), klp, what="kl_prior")
+    out["kl_prior"] = klp
+    # compute_Lt
+    pd = dc.PredictionData(graph_reconstruction=ref.dutils.PlaceHolder(X=lX, E=lE, y=None))
+    model.val_X_kl.reset(); model.val_E_kl.reset()
+    Lt = model.compute_Lt(bd, pd, test=False)
+    *_, oLt = O_dif.compute_Lt_terms(500, mx, me, X, E, X_t, E_t, lX, lE, mask, noise)
+    close(oLt, Lt, tol=1e-5, what="Lt")
+    out["Lt"] = Lt
+    # reverse-step probabilities + sampling
+    pX, pE = O_dif.reverse_step_probs(lX, lE, X_t, E_t, noise["beta_t"], noise["alpha_s_bar"], noise["alpha_t_bar"], mx, me)
+    out.update(rev_prob_X=pX, rev_prob_E=pE)
+    npz("posterior", X=X, E=E, mask=mask, X_t=X_t, E_t=E_t, logits_X=lX, logits_E=lE, mx=mx, me=me,
+        **{"n_" + k: v for k, v in noise.items()}, **out)
+
+
+# =============================================================================== G12 reverse step with the network, G13 common step
+def gen_full_steps():
+    model, kw, infos = make_full_model(phase="pretrain_drug", seed=1)
+    model.eval()
+    mx = torch.tensor(infos["dataset"]["node_marginals"]); me = torch.tensor(infos["dataset"]["edge_marginals"])
+    g = torch.Generator().manual_seed(40)
+    bs, n, cx, ce = 4, 9, 8, 5
+    X, E, mask = ragged_graph(bs, n, [9, 7, 5, 3], cx, ce, g)
+    sch = O_dif.Schedule(500)
+    gen_ = infos["general"]
+    dec_sd = {k[len("drug_decoder."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("drug_decoder.")}
+    gtk = kw["graph_transformer_kwargs"]
+
+    # ---- one reverse step from z_t (seeded)
+    torch.manual_seed(50)
+    eX = torch.empty(bs * n, cx).exponential_(1); eE = torch.empty(bs * n * n, ce).exponential_(1)
+    X_t, E_t = O_dif.sample_limit(mx, me, mask, eX, eE)
+    emb = torch.randn(bs, 32, generator=g)
+    s = torch.full((bs, 1), 498.0) / 500; t = torch.full((bs, 1), 499.0) / 500
+    torch.manual_seed(51)
+    with torch.no_grad():
+        zs = model.sample_p_zs_given_zt(s, t, X_t, E_t, emb, mask)
+    torch.manual_seed(51)
+    lcc = torch.randn(bs, n)
+    rX = torch.empty(bs * n, cx).exponential_(1); rE = torch.empty(bs * n * n, ce).exponential_(1)
+    with torch.no_grad():
+        Xe, ye = O_feat.extra_features(X_t, E_t, t, mask, lcc, gen_["max_n_nodes"], gen_["atom_valencies"], gen_["atom_weights"], gen_["max_weight"])
+        oX, oE, oy = O_den.graph_transformer(dec_sd, torch.cat([X_t, Xe], 2), E_t, torch.cat([emb, ye], 1), mask,
+                                             gtk["n_layers"], gtk["hidden_dims"]["n_head"], gtk["output_dims"])
+        pX, pE = O_dif.reverse_step_probs(oX, oE, X_t, E_t, sch.beta(t_normalized=t), sch.alpha_bar(t_normalized=s),
+                                          sch.alpha_bar(t_normalized=t), mx, me)
+        Xc, Ec = O_dif.sample_graph(pX, pE, mask, rX, rE)
+        Xs, Es = O_dif.one_hot_masked(Xc, Ec, mask, cx, ce)
+    assert torch.equal(Xs, zs.X) and torch.equal(Es, zs.E), "reverse step mismatch"
+    rec = dict(X_t=X_t, E_t=E_t, emb=emb, mask=mask, s=s, t=t, lcc_noise=lcc, expX=rX, expE=rE, X_s=zs.X, E_s=zs.E,
+               X_extra=Xe, y_extra=ye, logits_X=oX, logits_E=oE, prob_X=pX, prob_E=pE, mx=mx, me=me)
+
+    # ---- _common_step("train") in eval-dropout mode on a synthetic batch bypassing to_dense
+    model2, kw2, infos2 = make_full_model(phase="train", seed=2)
+    B = bs
+    feats_d = {"FP-Morgan": (torch.rand(B, 64, generator=g) < 0.15).float(), "EMB-BiomedGraph": torch.randn(B, 24, generator=g)}
+    feats_t = {"FP-ESP": (torch.rand(B, 48, generator=g) < 0.15).float(), "EMB-ESM": torch.randn(B, 40, generator=g), "EMB-NT": torch.randn(B, 20, generator=g)}
+    ydict = {"Y": (torch.rand(B, generator=g) < 0.4).float(), "Y_pKd": torch.randn(B, generator=g) + 6, "Y_pKi": torch.randn(B, generator=g) + 6,
+             "Y_KIBA": torch.randn(B, generator=g) + 11, "Y_pKd_mask": torch.tensor([True, False, True, True]),
+             "Y_pKi_mask": torch.tensor([False, True, False, True]), "Y_KIBA_mask": torch.tensor([True, True, False, False])}
+    batch = {"id": torch.arange(B), "y": ydict, "drug": {"features": feats_d, "representations": {"smiles": ["C"] * B}, "G": None},
+             "target": {"features": feats_t}}
+    dc = ref.dc
+    model2._extract_graph_data = lambda b: dc.GraphData(X=X.clone(), E=E.clone(), node_mask=mask)
+    # eval() freezes dropout; force the train-time lower bound on t by toggling only `training` of the top module
+    model2.eval()
+    object.__setattr__(model2, "training", True)
+    torch.manual_seed(60)
+    bd, ed, pdta, ld = model2._common_step(batch, "train")
+    total = ld.compute_loss(model2.weights)
+    total.backward()
+    gn = {k: p.grad.norm() for k, p in model2.named_parameters() if p.grad is not None}
+    gsel = {k: p.grad.detach().clone() for k, p in model2.named_parameters()
+            if p.grad is not None and (k.endswith("self_attn.e_mul.weight") or k.endswith("self_attn.q.weight") or
+                                       k.endswith("mlp_in_E.0.weight") or k.endswith("mlp_out_E.2.weight") or k.startswith("drug_kl_head"))}
+    # replay RNG stream: randint(t) -> exp X -> exp E -> randn lcc -> randn_like eps
+    torch.manual_seed(60)
+    t_int = torch.randint(0, 501, size=(B, 1)).float()
+    aX = torch.empty(B * n, cx).exponential_(1); aE = torch.empty(B * n * n, ce).exponential_(1)
+    lcc2 = torch.randn(B, n)
+    eps = torch.randn(B, 32)
+    assert torch.equal(t_int, bd.graph_data.noise_params["t_int"])
+    object.__setattr__(model2, "training", False)
+    rec2 = dict(X=X, E=E, mask=mask, t_int=t_int, expX=aX, expE=aE, lcc_noise=lcc2, eps=eps,
+                X_t=bd.graph_data.X_t.float(), E_t=bd.graph_data.E_t.float(), X_extra=bd.graph_data.X_extra, y_extra=bd.graph_data.y_extra,
+                drug_embedding=ed.drug_embedding, drug_mu=ed.drug_mu, drug_logvar=ed.drug_logvar, target_embedding=ed.target_embedding,
+                fused=ed.fused_embedding, pred_X=pdta.graph_reconstruction.X, pred_E=pdta.graph_reconstruction.E,
+                loss_accuracy=ld.accuracy, loss_complexity=ld.complexity, loss_contrastive=ld.contrastive,
+                loss_reconstruction=ld.reconstruction, loss_total=total.detach(),
+                feat_d=feats_d, feat_t=feats_t, y=ydict, sd={k: v for k, v in model2.state_dict().items()},
+                gradnorm=gn, grad=gsel, weights=torch.tensor(model2.weights), mx=torch.tensor(infos2["dataset"]["node_marginals"]),
+                me=torch.tensor(infos2["dataset"]["edge_marginals"]))
+    close(ed.drug_mu + eps * torch.exp(0.5 * ed.drug_logvar), ed.drug_embedding, what="eps replay")
+    npz("reverse_step", **rec, sd=dec_sd)
+    npz("common_step", **rec2)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    gen_schedule()
+    model, infos, X, E, mask, rec = gen_noise()
+    gen_features(model, infos, X, E, mask, rec)
+    gen_denoiser()
+    gen_heads()
+    gen_posterior(model, infos, X, E, mask, rec)
+    gen_full_steps()
+    print("all fixtures written and oracle == reference on every one")
