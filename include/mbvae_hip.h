@@ -1,0 +1,125 @@
+/* libmbvae_hip.so -- C ABI of the MI355X (gfx950) kernels behind the MB-VAE-DTI hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (fp32 unless noted; masks are uint8, class ids int64);
+ *     tensors are dense row-major with the feature dimension contiguous;
+ *   - nothing is allocated, freed or synchronised: outputs and workspaces are caller-owned, work is
+ *     enqueued on `stream` and the call returns immediately;
+ *   - return value: 0 ok, -1 invalid argument, -2 unsupported shape, -3 launch failure; no exceptions;
+ *   - re-entrant: no global mutable state.
+ * The reference has no native interface; each entry point replaces the sequence of PyTorch ops cited
+ * next to it (paths relative to the reference repository root).
+ */
+#ifndef MBVAE_HIP_H
+#define MBVAE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
+
+#define MBVAE_MASK_NONE 0
+#define MBVAE_MASK_NODE 1 /* row r = node (b,i):   keep iff mask[r] */
+#define MBVAE_MASK_EDGE 2 /* row r = pair (b,i,j): keep iff mask[b*n+i] && mask[b*n+j] */
+
+/* ---- Linear layers on the matrix cores (fp32 MFMA) -------------------------------------------------
+ * Replaces nn.Linear forward/backward plus the `* x_mask`, `* e_mask1 * e_mask2`, ReLU and Dropout that
+ * surround it in mb_vae_dti/training/models/graph_transformer.py:201-202,217-221,233,240,257 (NodeEdgeBlock),
+ * :134-144 (feed-forward blocks), :283-308,321-335 (in/out MLPs) and the encoder / head MLPs of
+ * mb_vae_dti/training/models/blocks.py:36-66,87-129 and heads.py:31-41,206-207.
+ *   y[M,N] = rowmask( dropout_p( act( x[M,K] @ w[N,K]^T + bias[N] ) ) )      act: 0 none, 1 ReLU
+ * workspace (optional, may be NULL) enables split-K for small M*N; any size is accepted. */
+int mbvae_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                     int64_t M, int64_t K, int64_t N, int act, const uint8_t* mask, int mask_mode, int n_nodes,
+                     float drop_p, uint64_t seed, int accumulate, void* workspace, int64_t ws_bytes,
+                     mbvae_stream_t stream);
+/* dx[M,K] (+)= pro(dy)[M,N] @ w[N,K], pro(dy) = (gate > 0 ? dy : 0) * gate_scale * rowmask   (gate may be NULL) */
+int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t M,
+                           int64_t K, int64_t N, const float* gate, float gate_scale, const uint8_t* mask,
+                           int mask_mode, int n_nodes, int accumulate, void* workspace, int64_t ws_bytes,
+                           mbvae_stream_t stream);
+/* dw[N,K] (+)= pro(dy)[M,N]^T @ x[M,K];  db[N] = column sums of pro(dy) (db may be NULL) */
+int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
+                            int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
+                            const uint8_t* mask, int mask_mode, int n_nodes, int accumulate, void* workspace,
+                            int64_t ws_bytes, mbvae_stream_t stream);
+
+/* ---- Edge-feature attention ------------------------------------------------------------------------
+ * Replaces graph_transformer.py:206-249 (Y = Q*K/sqrt(df); Y*(E1+1)+E2; FiLM by y; per-channel masked
+ * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx], E1,E2 [bs,n,n,dx] already
+ * masked; ye_add,ye_mul [bs,dx]; mask [bs,n].  P [bs,n,n,dx] is the input of e_out, wV [bs,n,dx],
+ * lse [bs,n,dx] (log-sum-exp per query row and channel, kept for backward).  dx % 4 == 0. */
+int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
+                        const float* ye_add, const float* ye_mul, const uint8_t* mask, float* P, float* wV,
+                        float* lse, int64_t bs, int64_t n, int64_t dx, float scale, mbvae_stream_t stream);
+int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
+                        const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+                        const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK, float* dV,
+                        float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx, float scale,
+                        mbvae_stream_t stream);
+
+/* ---- residual + dropout + LayerNorm ------------------------------------------------------------------
+ * Replaces `norm(X + dropout(newX))` of graph_transformer.py:125-144 (and nn.LayerNorm elsewhere with r = NULL). */
+int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                          float* mean, float* rstd, int64_t rows, int64_t D, float eps, float drop_p,
+                          uint64_t seed, mbvae_stream_t stream);
+int64_t mbvae_ln_residual_bwd_workspace(int64_t D);
+int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,
+                          const float* dy, float* dx, float* dr, float* dgamma, float* dbeta, int64_t rows,
+                          int64_t D, float drop_p, uint64_t seed, void* workspace, int64_t ws_bytes,
+                          mbvae_stream_t stream);
+
+/* ---- X->y / E->y pooling ---------------------------------------------------------------------------
+ * Replaces Xtoy / Etoy statistics, graph_transformer.py:40-46,57-65: x [bs,L,D] -> [bs,4D] = mean|min|max|
+ * unbiased std over L (L = n or n*n; padded entries included).  arg [bs,2,D] int32 = first argmin/argmax. */
+int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs, int64_t L, int64_t D,
+                         mbvae_stream_t stream);
+int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg, const float* dstats, float* dx,
+                         int64_t bs, int64_t L, int64_t D, int accumulate, mbvae_stream_t stream);
+
+/* ---- symmetrise + mask -----------------------------------------------------------------------------
+ * Replaces graph_transformer.py:322,327 (input) and :338,341,343 (output):
+ * out[b,i,j,:] = 0.5*(x[b,i,j,:] + x[b,j,i,:] (+ s[b,i,j,:D] + s[b,j,i,:D])) * pairmask * (zero_diag ? i!=j : 1).
+ * The op is self-adjoint, so the same call (s = NULL) maps output gradients to input gradients. */
+int mbvae_sym_mask(const float* x, const float* s, int64_t lds, const uint8_t* mask, float* out, int64_t bs,
+                   int64_t n, int64_t D, int zero_diag, mbvae_stream_t stream);
+
+/* ---- masked cross-entropy + per-class BCE trackers ---------------------------------------------------
+ * Replaces ReconstructionHead.forward, mb_vae_dti/training/models/heads.py:270-296, and CEPerClass.update,
+ * mb_vae_dti/training/metrics/molecular_metrics.py:77-94, in one pass over the logits.
+ * out[0] = sum CE over kept rows, out[1] = #kept rows, out[2+c] = sum BCEWithLogits(logit_c, target_c). */
+int64_t mbvae_masked_ce_workspace(void);
+int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, int64_t rows, int64_t C,
+                        void* workspace, int64_t ws_bytes, mbvae_stream_t stream);
+int mbvae_masked_ce_bwd(const float* logits, const float* target, const float* coef, float* dlogits, int64_t rows,
+                        int64_t C, mbvae_stream_t stream);
+
+/* ---- reparameterisation + KL -------------------------------------------------------------------------
+ * Replaces KLVariationalHead.reparameterize / kl_divergence, heads.py:209-228 (eps supplied by the caller). */
+int64_t mbvae_kl_workspace(void);
+int mbvae_kl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kl, int64_t numel,
+                         void* workspace, int64_t ws_bytes, mbvae_stream_t stream);
+int mbvae_kl_reparam_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* dkl,
+                         float* dmu, float* dlogvar, int64_t numel, mbvae_stream_t stream);
+
+/* ---- discrete diffusion ------------------------------------------------------------------------------
+ * mbvae_apply_noise replaces FullDTIModel.apply_noise's probability construction and sampling,
+ * mb_vae_dti/training/modules/full.py:485-500 + mb_vae_dti/training/diffusion/utils.py:124-162
+ * (get_Qt_bar: diffusion/discrete_noise.py:82-99).  expX [bs*n,cx] / expE [bs*n*n,ce] are Exp(1) draws.
+ * mbvae_reverse_sample replaces full.py:1120-1171 after the network call
+ * (compute_batched_over0_posterior_distribution: diffusion/utils.py:319-349). */
+int mbvae_apply_noise(const float* X0, const float* E0, const uint8_t* mask, const float* abar_t, const float* mx,
+                      const float* me, const float* expX, const float* expE, int64_t* Xc, int64_t* Ec, float* Xt,
+                      float* Et, int64_t bs, int64_t n, int64_t cx, int64_t ce, mbvae_stream_t stream);
+int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float* Xt, const float* Et,
+                         const uint8_t* mask, const float* beta_t, const float* abar_s, const float* abar_t,
+                         const float* mx, const float* me, const float* expX, const float* expE, int64_t* Xc,
+                         int64_t* Ec, float* Xs, float* Es, float* probX, float* probE, int64_t bs, int64_t n,
+                         int64_t cx, int64_t ce, mbvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

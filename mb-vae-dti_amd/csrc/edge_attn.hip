@@ -1,0 +1,229 @@
+// Edge-feature attention of the node/edge block: the n x n x dx streaming core.
+//
+//   Y[b,i,j,c]    = Q[b,i,c] * K[b,j,c] / sqrt(df) * (E1[b,i,j,c] + 1) + E2[b,i,j,c]
+//   P[b,i,j,c]    = ye_add[b,c] + (ye_mul[b,c] + 1) * Y[b,i,j,c]                (edge update, pre e_out)
+//   A[b,i,:,c]    = softmax over valid keys j of Y[b,i,:,c]     (one softmax PER CHANNEL c)
+//   wV[b,i,c]     = sum_j A[b,i,j,c] * V[b,j,c]
+//
+// Every channel has its own softmax, so this is an HBM-bound streaming kernel, not a GEMM:
+// forward reads E1,E2 and writes P (3 x bs*n*n*dx floats); backward reads E1,E2,dP and writes
+// dE1,dE2 (5 x).  Layout: channels contiguous; a lane owns 4 consecutive channels (16-byte
+// accesses), a wave covers 256 channels = one 1 KiB row segment per instruction.
+//
+// Forward: one wave per query row (b,i), online (running max / sum) softmax over j; also stores
+// lse = max + log(sum) per (b,i,c) so that backward can rebuild A without a second reduction.
+// Backward: every (i,j,c) element is independent once lse and wV are known.  One 1024-thread
+// workgroup per graph: wave w owns keys j = w, w+16, ... (dK/dV accumulate in registers over the
+// i loop, no cross-workgroup reduction), the per-query sums dQ[i] are combined across the 16 waves
+// with LDS float adds.
+#include "common.h"
+
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+#define F4_OP(out, expr)                                   \
+  {                                                        \
+    { const int _q = 0; (out).x = (expr); }                \
+    { const int _q = 1; (out).y = (expr); }                \
+    { const int _q = 2; (out).z = (expr); }                \
+    { const int _q = 3; (out).w = (expr); }                \
+  }
+__device__ __forceinline__ float f4get(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// grid: (ceil(n/4), ceil(dx/256), bs), block 256: wave = query row, lane = 4 channels
+__global__ __launch_bounds__(256) void edge_attn_fwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ E1, const float* __restrict__ E2,
+    const float* __restrict__ ye_add, const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
+    float* __restrict__ P, float* __restrict__ wV, float* __restrict__ lse, int n, int dx, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, i = blockIdx.x * 4 + wave;
+  const int c = blockIdx.y * 256 + lane * 4;
+  if (i >= n || c >= dx) return;
+  const int64_t node = (int64_t)b * n;
+  const float4 q = ld4(Q + (node + i) * dx + c);
+  const float4 ya = ld4(ye_add + (int64_t)b * dx + c);
+  float4 ym = ld4(ye_mul + (int64_t)b * dx + c);
+  ym.x += 1.f; ym.y += 1.f; ym.z += 1.f; ym.w += 1.f;
+  float4 qs; F4_OP(qs, f4get(q, _q) * scale);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  float4 l = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t rowbase = ((node + i) * n) * (int64_t)dx + c;
+#pragma unroll 4
+  for (int j = 0; j < n; ++j) {
+    const float4 e1 = ld4(E1 + rowbase + (int64_t)j * dx);
+    const float4 e2 = ld4(E2 + rowbase + (int64_t)j * dx);
+    const float4 k = ld4(K + (node + j) * dx + c);
+    const float4 v = ld4(V + (node + j) * dx + c);
+    float4 y; F4_OP(y, f4get(qs, _q) * f4get(k, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
+    float4 p; F4_OP(p, f4get(ya, _q) + f4get(ym, _q) * f4get(y, _q));
+    st4(P + rowbase + (int64_t)j * dx, p);
+    if (mask[node + j]) {
+      float4 mn; F4_OP(mn, fmaxf(f4get(m, _q), f4get(y, _q)));
+      float4 corr; F4_OP(corr, __expf(f4get(m, _q) - f4get(mn, _q)));
+      float4 w; F4_OP(w, __expf(f4get(y, _q) - f4get(mn, _q)));
+      F4_OP(l, f4get(l, _q) * f4get(corr, _q) + f4get(w, _q));
+      F4_OP(acc, f4get(acc, _q) * f4get(corr, _q) + f4get(w, _q) * f4get(v, _q));
+      m = mn;
+    }
+  }
+  float4 o, s;
+  F4_OP(o, f4get(l, _q) > 0.f ? f4get(acc, _q) / f4get(l, _q) : 0.f);
+  F4_OP(s, f4get(l, _q) > 0.f ? f4get(m, _q) + __logf(f4get(l, _q)) : INFINITY);
+  st4(wV + (node + i) * dx + c, o);
+  st4(lse + (node + i) * dx + c, s);
+}
+
+// grid: (ceil(dx/256), ceil(n/32), bs), block 1024: wave w owns keys j = 32*blockIdx.y + w + 16*jj (jj < 2),
+// lane = 4 channels.  dQ/dye_* are accumulated with global float adds across the key groups (zeroed by the host).
+#define EA_JPW 2
+#define EA_ROWS 64
+__global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ E1, const float* __restrict__ E2,
+    const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
+    const float* __restrict__ wV, const float* __restrict__ lse,
+    const float* __restrict__ dP, const float* __restrict__ dwV,
+    float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dQ, float* __restrict__ dK,
+    float* __restrict__ dV, float* __restrict__ dye_add, float* __restrict__ dye_mul, int n, int dx, float scale) {
+  __shared__ float dq_acc[EA_ROWS * 256];
+  __shared__ float dya_acc[256], dym_acc[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int cbase = blockIdx.x * 256;
+  const bool active = c < dx;
+  const int64_t node = (int64_t)b * n;
+  if (threadIdx.x < 256) { dya_acc[threadIdx.x] = 0.f; dym_acc[threadIdx.x] = 0.f; }
+
+  float4 ks[EA_JPW], dk[EA_JPW], dv[EA_JPW];
+  bool ok[EA_JPW];
+  float4 ym = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 dya = make_float4(0.f, 0.f, 0.f, 0.f), dym = dya;
+#pragma unroll
+  for (int jj = 0; jj < EA_JPW; ++jj) {
+    const int j = blockIdx.y * 32 + wave + 16 * jj;
+    dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj]; ks[jj] = dk[jj]; ok[jj] = false;
+    if (active && j < n) {
+      const float4 k = ld4(K + (node + j) * dx + c);
+      F4_OP(ks[jj], f4get(k, _q) * scale);
+      ok[jj] = mask[node + j] != 0;
+    }
+  }
+  if (active) {
+    const float4 t = ld4(ye_mul + (int64_t)b * dx + c);
+    ym.x += t.x; ym.y += t.y; ym.z += t.z; ym.w += t.w;
+  }
+
+  for (int i0 = 0; i0 < n; i0 += EA_ROWS) {
+    const int rows = min(EA_ROWS, n - i0);
+    for (int t = threadIdx.x; t < rows * 256; t += 1024) dq_acc[t] = 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int ii = 0; ii < rows; ++ii) {
+        const int i = i0 + ii;
+        const float4 q = ld4(Q + (node + i) * dx + c);
+        const float4 ls = ld4(lse + (node + i) * dx + c);
+        const float4 wv = ld4(wV + (node + i) * dx + c);
+        const float4 dwv = ld4(dwV + (node + i) * dx + c);
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t rowbase = ((node + i) * n) * (int64_t)dx + c;
+#pragma unroll
+        for (int jj = 0; jj < EA_JPW; ++jj) {
+          const int j = blockIdx.y * 32 + wave + 16 * jj;
+          if (j < n) {
+            const int64_t off = rowbase + (int64_t)j * dx;
+            const float4 e1 = ld4(E1 + off);
+            const float4 e2 = ld4(E2 + off);
+            const float4 dp = ld4(dP + off);
+            const float4 vj = ld4(V + (node + j) * dx + c);
+            float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));
+            float4 y; F4_OP(y, f4get(qk, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
+            float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);
+            float4 dy; F4_OP(dy, f4get(dp, _q) * f4get(ym, _q) +
+                                   f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q)));
+            float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));
+            st4(dE1 + off, t);
+            st4(dE2 + off, dy);
+            float4 g; F4_OP(g, f4get(dy, _q) * (f4get(e1, _q) + 1.f));
+            F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));
+            F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);
+            F4_OP(dv[jj], f4get(dv[jj], _q) + f4get(a, _q) * f4get(dwv, _q));
+            F4_OP(dya, f4get(dya, _q) + f4get(dp, _q));
+            F4_OP(dym, f4get(dym, _q) + f4get(dp, _q) * f4get(y, _q));
+          }
+        }
+        float* slot = &dq_acc[ii * 256 + lane * 4];
+        atomicAdd(slot + 0, dq.x); atomicAdd(slot + 1, dq.y); atomicAdd(slot + 2, dq.z); atomicAdd(slot + 3, dq.w);
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < rows * 256; t += 1024) {
+      const int ii = t >> 8, cc = t & 255;
+      if (cbase + cc < dx) atomicAdd(&dQ[(node + i0 + ii) * dx + cbase + cc], dq_acc[t]);
+    }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int jj = 0; jj < EA_JPW; ++jj) {
+      const int j = blockIdx.y * 32 + wave + 16 * jj;
+      if (j < n) { st4(dK + (node + j) * dx + c, dk[jj]); st4(dV + (node + j) * dx + c, dv[jj]); }
+    }
+    atomicAdd(&dya_acc[lane * 4 + 0], dya.x); atomicAdd(&dya_acc[lane * 4 + 1], dya.y);
+    atomicAdd(&dya_acc[lane * 4 + 2], dya.z); atomicAdd(&dya_acc[lane * 4 + 3], dya.w);
+    atomicAdd(&dym_acc[lane * 4 + 0], dym.x); atomicAdd(&dym_acc[lane * 4 + 1], dym.y);
+    atomicAdd(&dym_acc[lane * 4 + 2], dym.z); atomicAdd(&dym_acc[lane * 4 + 3], dym.w);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256 && cbase + threadIdx.x < dx) {
+    atomicAdd(&dye_add[(int64_t)b * dx + cbase + threadIdx.x], dya_acc[threadIdx.x]);
+    atomicAdd(&dye_mul[(int64_t)b * dx + cbase + threadIdx.x], dym_acc[threadIdx.x]);
+  }
+}
+
+static bool ea_aligned(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+// Q,K,V [bs,n,dx] (masked), E1,E2 [bs,n,n,dx] (masked), ye_add,ye_mul [bs,dx], mask [bs,n] (u8)
+// -> P [bs,n,n,dx], wV [bs,n,dx], lse [bs,n,dx].   scale = 1/sqrt(df).
+int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
+                        const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                        float* P, float* wV, float* lse, int64_t bs, int64_t n, int64_t dx, float scale,
+                        hipStream_t stream) {
+  if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
+  if (bs > 65535 || n > 0x7fffffff / 4) return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {Q, K, V, E1, E2, ye_add, ye_mul, P, wV, lse};
+  for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
+  if (!mask) return MBVAE_EINVAL;
+  dim3 grid((unsigned)((n + 3) / 4), (unsigned)((dx + 255) / 256), (unsigned)bs);
+  hipLaunchKernelGGL(edge_attn_fwd_kernel, grid, dim3(256), 0, stream, Q, K, V, E1, E2, ye_add, ye_mul, mask,
+                     P, wV, lse, (int)n, (int)dx, scale);
+  return mbvae_launch_status();
+}
+
+// Gradients of the above given dP [bs,n,n,dx] and dwV [bs,n,dx].
+// Writes dE1,dE2 [bs,n,n,dx], dQ,dK,dV [bs,n,dx], dye_add,dye_mul [bs,dx].
+int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
+                        const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+                        const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
+                        float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
+                        float scale, hipStream_t stream) {
+  if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
+  if (bs > 65535 || n > 32 * 65535) return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};
+  for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
+  if (!mask) return MBVAE_EINVAL;
+  if (hipMemsetAsync(dQ, 0, sizeof(float) * bs * n * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  if (hipMemsetAsync(dye_add, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  if (hipMemsetAsync(dye_mul, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  dim3 grid((unsigned)((dx + 255) / 256), (unsigned)((n + 31) / 32), (unsigned)bs);
+  hipLaunchKernelGGL(edge_attn_bwd_kernel, grid, dim3(1024), 0, stream, Q, K, V, E1, E2, ye_mul, mask, wV, lse,
+                     dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale);
+  return mbvae_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+// fp32 projection GEMMs on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+//
+// One kernel template serves the three products a Linear layer needs
+//   forward        y  = epi(x  @ W^T + b)      "NT": A = x [M,K] (k contiguous),  B = W [N,K] (k contiguous)
+//   input grad     dx = pro(dy) @ W            "NN": A = dy [M,K'] (k contiguous), B = W [K',N] (n contiguous)
+//   weight grad    dW = pro(dy)^T @ x, db      "TN": A = dy [R,M'] (m contiguous), B = x [R,N'] (n contiguous), R = rows
+// with the reference's masking / ReLU / dropout folded into the operand prologue and the epilogue,
+// so the [bs*n*n, d] edge tensors are never touched by a stand-alone elementwise pass.
+//
+// Tiling: 256 threads = 4 waves, BK = 32.  Operand tiles live in LDS k-major (As[k][m], Bs[k][n]) so
+// that the MFMA operand fetch (lane l -> A[m = l&31][k = l>>5]) is a stride-1, conflict-free
+// ds_read_b32 for each 32-lane half.  Operands whose reduction index is contiguous in memory are
+// transposed on the way into LDS with row stride == 1 (mod 32) (conflict-free scatter); operands
+// that are already m/n-contiguous are copied with 16-byte LDS stores.  The next k-tile is fetched
+// into registers while the current one is multiplied.  Tall reductions (weight grads over bs*n*n
+// rows, small-batch y-path products) are split over blockIdx.z into a workspace and summed by a
+// second kernel that also applies the epilogue, which keeps results bitwise reproducible.
+#include "common.h"
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  // prologue on A: a = (gate > 0 ? a : 0) * gate_scale * keep(row)
+  const float* a_gate; float a_gate_scale;
+  const uint8_t* mask; int a_mask_mode; int c_mask_mode; int n_nodes;
+  // epilogue on C: +bias[n], relu, dropout, row mask, (+= C)
+  const float* bias; int act; float drop_p; uint64_t seed; int accumulate;
+  // TN only: column sums of pro(A) (bias gradient)
+  float* colsum;
+  // split-K
+  int k_per_split; float* partial; float* partial_colsum;
+};
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col, float keep_row) {
+  if (g.bias) v += g.bias[col];
+  if (g.act == 1) v = fmaxf(v, 0.f);
+  if (g.drop_p > 0.f) v *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
+  v *= keep_row;
+  if (g.accumulate) v += g.C[(int64_t)row * g.ldc + col];
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int LDAS = A_KC ? BM + 1 : BM + 4;
+  constexpr int LDBS = B_KC ? BN + 1 : BN + 4;
+  constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // staged floats per thread
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __align__(16) float smem[BK * LDAS + BK * LDBS];
+  float* As = smem;
+  float* Bs = smem + BK * LDAS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const bool vecA = (((uintptr_t)g.A & 15) == 0) && ((g.lda & 3) == 0) &&
+                    (g.a_gate == nullptr || ((uintptr_t)g.a_gate & 15) == 0);
+  const bool vecB = (((uintptr_t)g.B & 15) == 0) && ((g.ldb & 3) == 0);
+
+  float ra[RA], rb[RB];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  float colsum = 0.f;
+
+  auto fetch = [&](int kt) {
+    // ---- A
+    if (A_KC) {
+#pragma unroll
+      for (int p = 0; p < BM / 32; ++p) {
+        const int row = m0 + (tid >> 3) + 32 * p;
+        const int kc = kt + (tid & 7) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < g.M) {
+          const int64_t off = (int64_t)row * g.lda + kc;
+          const float keep = mbvae_row_keep(g.mask, g.a_mask_mode, row, g.n_nodes) * g.a_gate_scale;
+          if (vecA && kc + 3 < kend) {
+            float4 t = *reinterpret_cast<const float4*>(g.A + off);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            if (g.a_gate) {
+              float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
+              v[0] = q.x > 0.f ? v[0] : 0.f; v[1] = q.y > 0.f ? v[1] : 0.f;
+              v[2] = q.z > 0.f ? v[2] : 0.f; v[3] = q.w > 0.f ? v[3] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (kc + q < kend) {
+                float t = g.A[off + q];
+                if (g.a_gate && !(g.a_gate[off + q] > 0.f)) t = 0.f;
+                v[q] = t;
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] *= keep;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[p * 4 + q] = v[q];
+      }
+    } else {
+      constexpr int ROWS_PER_PASS = 1024 / BM;
+#pragma unroll
+      for (int p = 0; p < BM / 32; ++p) {
+        const int mq = tid % (BM / 4);
+        const int krow = kt + tid / (BM / 4) + ROWS_PER_PASS * p;
+        const int mc = m0 + mq * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (krow < kend) {
+          const int64_t off = (int64_t)krow * g.lda + mc;
+          const float keep = mbvae_row_keep(g.mask, g.a_mask_mode, krow, g.n_nodes) * g.a_gate_scale;
+          if (vecA && mc + 3 < g.M) {
+            float4 t = *reinterpret_cast<const float4*>(g.A + off);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            if (g.a_gate) {
+              float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
+              v[0] = q.x > 0.f ? v[0] : 0.f; v[1] = q.y > 0.f ? v[1] : 0.f;
+              v[2] = q.z > 0.f ? v[2] : 0.f; v[3] = q.w > 0.f ? v[3] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (mc + q < g.M) {
+                float t = g.A[off + q];
+                if (g.a_gate && !(g.a_gate[off + q] > 0.f)) t = 0.f;
+                v[q] = t;
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] *= keep;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[p * 4 + q] = v[q];
+      }
+    }
+    // ---- B
+    if (B_KC) {
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) {
+        const int row = n0 + (tid >> 3) + 32 * p;
+        const int kc = kt + (tid & 7) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < g.N) {
+          const int64_t off = (int64_t)row * g.ldb + kc;
+          if (vecB && kc + 3 < kend) {
+            float4 t = *reinterpret_cast<const float4*>(g.B + off);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (kc + q < kend) v[q] = g.B[off + q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[p * 4 + q] = v[q];
+      }
+    } else {
+      constexpr int ROWS_PER_PASS = 1024 / BN;
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) {
+        const int nq = tid % (BN / 4);
+        const int krow = kt + tid / (BN / 4) + ROWS_PER_PASS * p;
+        const int nc = n0 + nq * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (krow < kend) {
+          const int64_t off = (int64_t)krow * g.ldb + nc;
+          if (vecB && nc + 3 < g.N) {
+            float4 t = *reinterpret_cast<const float4*>(g.B + off);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (nc + q < g.N) v[q] = g.B[off + q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[p * 4 + q] = v[q];
+      }
+    }
+  };
+
+  auto commit = [&]() {
+    if (A_KC) {
+#pragma unroll
+      for (int p = 0; p < BM / 32; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) As[((tid & 7) * 4 + q) * LDAS + (tid >> 3) + 32 * p] = ra[p * 4 + q];
+    } else {
+      constexpr int ROWS_PER_PASS = 1024 / BM;
+#pragma unroll
+      for (int p = 0; p < BM / 32; ++p) {
+        float4 t = make_float4(ra[p * 4], ra[p * 4 + 1], ra[p * 4 + 2], ra[p * 4 + 3]);
+        *reinterpret_cast<float4*>(&As[(tid / (BM / 4) + ROWS_PER_PASS * p) * LDAS + (tid % (BM / 4)) * 4]) = t;
+      }
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[((tid & 7) * 4 + q) * LDBS + (tid >> 3) + 32 * p] = rb[p * 4 + q];
+    } else {
+      constexpr int ROWS_PER_PASS = 1024 / BN;
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) {
+        float4 t = make_float4(rb[p * 4], rb[p * 4 + 1], rb[p * 4 + 2], rb[p * 4 + 3]);
+        *reinterpret_cast<float4*>(&Bs[(tid / (BN / 4) + ROWS_PER_PASS * p) * LDBS + (tid % (BN / 4)) * 4]) = t;
+      }
+    }
+  };
+
+  const bool want_colsum = (g.colsum != nullptr || g.partial_colsum != nullptr) && n0 == 0;
+  if (kbeg < kend) fetch(kbeg);
+  for (int kt = kbeg; kt < kend; kt += BK) {
+    __syncthreads();                 // previous tile fully consumed
+    commit();
+    __syncthreads();
+    if (kt + BK < kend) fetch(kt + BK);
+    if (want_colsum && tid < BM) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) colsum += As[k * LDAS + tid];
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + h) * LDAS + (wm * TM + i) * 32 + r];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + h) * LDBS + (wn * TN + j) * 32 + r];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- write back.  C/D layout of the 32x32 tile: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+  const bool split = g.partial != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (row >= g.M) continue;
+      const float keep = split ? 1.f : mbvae_row_keep(g.mask, g.c_mask_mode, row, g.n_nodes);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + r;
+        if (col >= g.N) continue;
+        if (split)
+          g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][v];
+        else
+          g.C[(int64_t)row * g.ldc + col] = gemm_epilogue(g, acc[i][j][v], row, col, keep);
+      }
+    }
+  if (want_colsum && tid < BM && m0 + tid < g.M) {
+    if (split) g.partial_colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = colsum;
+    else g.colsum[m0 + tid] = colsum;
+  }
+}
+
+__global__ void gemm_reduce_kernel(GemmArgs g, int splits) {
+  const int64_t total = (int64_t)g.M * g.N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + g.M; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < total) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += g.partial[(int64_t)z * total + e];
+      const int row = (int)(e / g.N), col = (int)(e - (int64_t)row * g.N);
+      const float keep = mbvae_row_keep(g.mask, g.c_mask_mode, row, g.n_nodes);
+      g.C[(int64_t)row * g.ldc + col] = gemm_epilogue(g, s, row, col, keep);
+    } else if (g.colsum) {
+      const int64_t m = e - total;
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += g.partial_colsum[(int64_t)z * g.M + m];
+      g.colsum[m] = s;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
+  if (!g.A || !g.B || !g.C) return MBVAE_EINVAL;
+  int BM, BN;
+  if (g.M <= 64 || g.N <= 32 || (int64_t)g.M * g.N <= 512 * 1024) { BM = 64; BN = 64; }
+  else if (g.N <= 64) { BM = 128; BN = 64; }
+  else { BM = 128; BN = 128; }
+  const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  // split the reduction until ~2 blocks per CU are in flight
+  int splits = 1;
+  if (tiles < 256 && g.K >= 256) {
+    splits = (int)std::min<int64_t>(512 / tiles, g.K / 128);
+    const int64_t per = ((int64_t)g.M * g.N + g.M) * 4;
+    if (workspace == nullptr || ws_bytes < per * 2) splits = 1;
+    else splits = (int)std::min<int64_t>(splits, ws_bytes / per);
+    if (splits < 1) splits = 1;
+  }
+  g.k_per_split = ((g.K + splits - 1) / splits + 31) / 32 * 32;
+  splits = (g.K + g.k_per_split - 1) / g.k_per_split;
+  if (splits > 1) {
+    g.partial = (float*)workspace;
+    g.partial_colsum = g.partial + (int64_t)splits * g.M * g.N;
+  } else {
+    g.partial = nullptr; g.partial_colsum = nullptr;
+  }
+  dim3 grid((unsigned)tiles, 1, (unsigned)splits), block(256);
+  if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC>), grid, block, 0, stream, g);
+  else if (BN == 64) hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 4, 1, A_KC, B_KC>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, A_KC, B_KC>), grid, block, 0, stream, g);
+  if (splits > 1) {
+    const int64_t total = (int64_t)g.M * g.N + g.M;
+    int blocks = (int)std::min<int64_t>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g, splits);
+  }
+  return mbvae_launch_status();
+}
+
+extern "C" {
+
+// y[M,N] = mask_rows( dropout( act( x[M,K] @ w[N,K]^T + bias ) ) )  (+= y if accumulate)
+int mbvae_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                     int64_t M, int64_t K, int64_t N, int act, const uint8_t* mask, int mask_mode, int n_nodes,
+                     float drop_p, uint64_t seed, int accumulate, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  GemmArgs g = {};
+  g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.lda = ldx; g.ldb = K; g.ldc = ldy;
+  g.a_gate_scale = 1.f; g.mask = mask; g.c_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.bias = bias; g.act = act; g.drop_p = drop_p; g.seed = seed; g.accumulate = accumulate;
+  return gemm_dispatch<true, true>(g, workspace, ws_bytes, stream);
+}
+
+// dx[M,K] (+)= pro(dy)[M,N] @ w[N,K];  pro(dy) = (gate > 0 ? dy : 0) * gate_scale * keep(row)
+int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
+                           int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
+                           const uint8_t* mask, int mask_mode, int n_nodes, int accumulate,
+                           void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (gate && lddy != N) return MBVAE_EINVAL;     // gate shares dy's layout
+  GemmArgs g = {};
+  g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = (int)K; g.K = (int)N;
+  g.lda = lddy; g.ldb = K; g.ldc = lddx;
+  g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.accumulate = accumulate;
+  return gemm_dispatch<true, false>(g, workspace, ws_bytes, stream);
+}
+
+// dw[N,K] = pro(dy)[M,N]^T @ x[M,K];  db[N] = column sums of pro(dy)  (db may be null)
+int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
+                            int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
+                            const uint8_t* mask, int mask_mode, int n_nodes, int accumulate,
+                            void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (gate && lddy != N) return MBVAE_EINVAL;
+  GemmArgs g = {};
+  g.A = dy; g.B = x; g.C = dw; g.M = (int)N; g.N = (int)K; g.K = (int)M;
+  g.lda = lddy; g.ldb = ldx; g.ldc = K;
+  g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.accumulate = accumulate; g.colsum = db;
+  return gemm_dispatch<false, false>(g, workspace, ws_bytes, stream);
+}
+
+}  // extern "C"

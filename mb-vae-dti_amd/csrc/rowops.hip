@@ -1,0 +1,487 @@
+// Row-wise streaming kernels of the transformer layer (all HBM-bound):
+//   * residual + dropout + LayerNorm, forward and backward          (XEyTransformerLayer norm*1 / norm*2)
+//   * mean|min|max|std pooling over nodes / node pairs, fwd + bwd   (Xtoy / Etoy)
+//   * symmetrise + mask of an edge tensor                           (GraphTransformer input / output)
+// Layout everywhere: feature dimension contiguous, one lane owns 4 consecutive features
+// (16-byte accesses); a group of LPR = D/4 lanes (a power of two, <= 64) owns a row so that a
+// 64-feature edge row uses 16 lanes and a wave streams 4 rows per instruction.
+#include "common.h"
+#include <algorithm>
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm( x + dropout(r) ) * gamma + beta.   D = LPR*4*VPL features per row.
+// grid-stride over row groups; block 256.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_res_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, int64_t rows, float eps,
+                                                         float drop_p, uint64_t seed) {
+  constexpr int D = LPR * 4 * VPL;
+  const int sub = threadIdx.x % LPR;
+  const int64_t rows_per_block = 256 / LPR;
+  float4 gm[VPL], bt[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) { gm[v] = ld4(gamma + (v * LPR + sub) * 4); bt[v] = ld4(beta + (v * LPR + sub) * 4); }
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / LPR; row < rows;
+       row += (int64_t)gridDim.x * rows_per_block) {
+    float4 z[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int64_t off = row * D + (v * LPR + sub) * 4;
+      z[v] = ld4(x + off);
+      if (r) {
+        const float4 t = ld4(r + off);
+        if (drop_p > 0.f) {
+          z[v].x += t.x * mbvae_drop_scale(drop_p, seed, off + 0);
+          z[v].y += t.y * mbvae_drop_scale(drop_p, seed, off + 1);
+          z[v].z += t.z * mbvae_drop_scale(drop_p, seed, off + 2);
+          z[v].w += t.w * mbvae_drop_scale(drop_p, seed, off + 3);
+        } else { z[v].x += t.x; z[v].y += t.y; z[v].z += t.z; z[v].w += t.w; }
+      }
+      s += (z[v].x + z[v].y) + (z[v].z + z[v].w);
+    }
+    const float mean = group_sum<LPR>(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float a = z[v].x - mean, b = z[v].y - mean, c = z[v].z - mean, d = z[v].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / D) + eps);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      float4 o;
+      o.x = (z[v].x - mean) * rstd * gm[v].x + bt[v].x;
+      o.y = (z[v].y - mean) * rstd * gm[v].y + bt[v].y;
+      o.z = (z[v].z - mean) * rstd * gm[v].z + bt[v].z;
+      o.w = (z[v].w - mean) * rstd * gm[v].w + bt[v].w;
+      st4(y + row * D + (v * LPR + sub) * 4, o);
+    }
+    if (sub == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  }
+}
+
+// Backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma;  dx = dz;  dr = dz * dropscale.
+// Per-block partial sums of dgamma/dbeta go to part[blockIdx.x][2][D] (summed by colsum_partials_kernel).
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                         const float* __restrict__ rstd_in, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ dr,
+                                                         float* __restrict__ part, int64_t rows, float drop_p, uint64_t seed) {
+  constexpr int D = LPR * 4 * VPL;
+  constexpr int GROUPS = 256 / LPR;
+  __shared__ float red[2 * 256 * 4];
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  float4 gm[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    gm[v] = ld4(gamma + (v * LPR + sub) * 4);
+    dg[v] = make_float4(0.f, 0.f, 0.f, 0.f); db[v] = dg[v];
+  }
+  for (int64_t row = (int64_t)blockIdx.x * GROUPS + grp; row < rows; row += (int64_t)gridDim.x * GROUPS) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[VPL], g[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int64_t off = row * D + (v * LPR + sub) * 4;
+      float4 z = ld4(x + off);
+      if (r) {
+        const float4 t = ld4(r + off);
+        if (drop_p > 0.f) {
+          z.x += t.x * mbvae_drop_scale(drop_p, seed, off + 0);
+          z.y += t.y * mbvae_drop_scale(drop_p, seed, off + 1);
+          z.z += t.z * mbvae_drop_scale(drop_p, seed, off + 2);
+          z.w += t.w * mbvae_drop_scale(drop_p, seed, off + 3);
+        } else { z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w; }
+      }
+      const float4 d = ld4(dy + off);
+      xh[v] = make_float4((z.x - mean) * rstd, (z.y - mean) * rstd, (z.z - mean) * rstd, (z.w - mean) * rstd);
+      g[v] = make_float4(d.x * gm[v].x, d.y * gm[v].y, d.z * gm[v].z, d.w * gm[v].w);
+      s1 += (g[v].x + g[v].y) + (g[v].z + g[v].w);
+      s2 += (g[v].x * xh[v].x + g[v].y * xh[v].y) + (g[v].z * xh[v].z + g[v].w * xh[v].w);
+      dg[v].x += d.x * xh[v].x; dg[v].y += d.y * xh[v].y; dg[v].z += d.z * xh[v].z; dg[v].w += d.w * xh[v].w;
+      db[v].x += d.x; db[v].y += d.y; db[v].z += d.z; db[v].w += d.w;
+    }
+    const float m1 = group_sum<LPR>(s1) * (1.f / D), m2 = group_sum<LPR>(s2) * (1.f / D);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int64_t off = row * D + (v * LPR + sub) * 4;
+      float4 dz;
+      dz.x = rstd * (g[v].x - m1 - xh[v].x * m2);
+      dz.y = rstd * (g[v].y - m1 - xh[v].y * m2);
+      dz.z = rstd * (g[v].z - m1 - xh[v].z * m2);
+      dz.w = rstd * (g[v].w - m1 - xh[v].w * m2);
+      st4(dx + off, dz);
+      if (dr) {
+        if (drop_p > 0.f) {
+          dz.x *= mbvae_drop_scale(drop_p, seed, off + 0);
+          dz.y *= mbvae_drop_scale(drop_p, seed, off + 1);
+          dz.z *= mbvae_drop_scale(drop_p, seed, off + 2);
+          dz.w *= mbvae_drop_scale(drop_p, seed, off + 3);
+        }
+        st4(dr + off, dz);
+      }
+    }
+  }
+  // reduce dgamma/dbeta over the GROUPS row groups of this block (fixed order -> deterministic)
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    __syncthreads();
+    float* a = red + threadIdx.x * 4;
+    float* b = red + 1024 + threadIdx.x * 4;
+    a[0] = dg[v].x; a[1] = dg[v].y; a[2] = dg[v].z; a[3] = dg[v].w;
+    b[0] = db[v].x; b[1] = db[v].y; b[2] = db[v].z; b[3] = db[v].w;
+    __syncthreads();
+    if (threadIdx.x < LPR * 4) {
+      const int lanei = threadIdx.x / 4, comp = threadIdx.x % 4;
+      float sg = 0.f, sb = 0.f;
+      for (int gidx = 0; gidx < GROUPS; ++gidx) {
+        sg += red[(gidx * LPR + lanei) * 4 + comp];
+        sb += red[1024 + (gidx * LPR + lanei) * 4 + comp];
+      }
+      const int col = (v * LPR + lanei) * 4 + comp;
+      part[((int64_t)blockIdx.x * 2 + 0) * D + col] = sg;
+      part[((int64_t)blockIdx.x * 2 + 1) * D + col] = sb;
+    }
+  }
+}
+
+// out[c] = sum_p part[p][c], c < width  (second stage of the per-block partial sums)
+__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int width) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * width + c];
+  out[c] = s;
+}
+
+template <int LPR, int VPL>
+static int ln_launch(bool fwd, const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                     float* mean, float* rstd, const float* dy, float* dx, float* dr, float* dgamma, float* dbeta,
+                     float* part, int64_t part_floats, int64_t rows, float eps, float drop_p, uint64_t seed,
+                     hipStream_t stream) {
+  constexpr int D = LPR * 4 * VPL;
+  const int64_t rpb = 256 / LPR;
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  if (fwd) {
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((ln_res_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, beta, y,
+                       mean, rstd, rows, eps, drop_p, seed);
+  } else {
+    if (blocks > 1024) blocks = 1024;
+    if (part_floats < blocks * 2 * D) blocks = part_floats / (2 * D);
+    if (blocks < 1) return MBVAE_EINVAL;
+    hipLaunchKernelGGL((ln_res_bwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean,
+                       rstd, dy, dx, dr, part, rows, drop_p, seed);
+    // part is [blocks][2][D]: view as [blocks][2D] and sum -> [2D] = dgamma | dbeta (contiguous in `part` tail)
+    float* tail = part + blocks * 2 * D;
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, part, tail, (int)blocks, 2 * D);
+    if (hipMemcpyAsync(dgamma, tail, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
+    if (hipMemcpyAsync(dbeta, tail + D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  }
+  return mbvae_launch_status();
+}
+
+static int ln_dispatch(bool fwd, int64_t D, const float* x, const float* r, const float* gamma, const float* beta,
+                       float* y, float* mean, float* rstd, const float* dy, float* dx, float* dr, float* dgamma,
+                       float* dbeta, float* part, int64_t part_floats, int64_t rows, float eps, float drop_p,
+                       uint64_t seed, hipStream_t stream) {
+#define LN_CASE(dd, lpr, vpl)                                                                                        \
+  if (D == dd)                                                                                                       \
+    return ln_launch<lpr, vpl>(fwd, x, r, gamma, beta, y, mean, rstd, dy, dx, dr, dgamma, dbeta, part, part_floats, \
+                               rows, eps, drop_p, seed, stream);
+  LN_CASE(16, 4, 1) LN_CASE(32, 8, 1) LN_CASE(64, 16, 1) LN_CASE(128, 32, 1) LN_CASE(256, 64, 1)
+  LN_CASE(512, 64, 2) LN_CASE(768, 64, 3) LN_CASE(1024, 64, 4) LN_CASE(1536, 64, 6) LN_CASE(2048, 64, 8)
+#undef LN_CASE
+  return MBVAE_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pooling: x [bs, L, D] -> stats [bs, 4D] = mean | min | max | unbiased std over L, arg [bs, 2, D] (int32)
+// One 512-thread block per (graph, 256-feature chunk); lane owns 4 features, row groups stride over L.
+// Mean/variance use Welford updates per thread and Chan's pairwise merge across threads (stable in fp32).
+struct Moments { float n, mean, m2; };
+__device__ __forceinline__ void mom_add(Moments& a, float x) {
+  a.n += 1.f; const float d = x - a.mean; a.mean += d / a.n; a.m2 += d * (x - a.mean);
+}
+__device__ __forceinline__ void mom_merge(Moments& a, const Moments& b) {
+  if (b.n == 0.f) return;
+  const float n = a.n + b.n, d = b.mean - a.mean;
+  a.mean += d * (b.n / n); a.m2 += b.m2 + d * d * (a.n * b.n / n); a.n = n;
+}
+
+__global__ __launch_bounds__(512) void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                        int* __restrict__ arg, int L, int D) {
+  extern __shared__ float sm[];
+  const int lpr = min(64, D / 4);                 // lanes per row (power of two)
+  const int groups = 512 / lpr;
+  const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  const int b = blockIdx.y, c = blockIdx.x * 256 + sub * 4;
+  const bool active = c < D;
+  Moments mo[4]; float mn[4], mx[4]; int amn[4], amx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { mo[q] = {0.f, 0.f, 0.f}; mn[q] = INFINITY; mx[q] = -INFINITY; amn[q] = 0x7fffffff; amx[q] = 0x7fffffff; }
+  if (active)
+    for (int l = grp; l < L; l += groups) {
+      const float4 v = ld4(x + ((int64_t)b * L + l) * D + c);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mom_add(mo[q], vv[q]);
+        if (vv[q] < mn[q]) { mn[q] = vv[q]; amn[q] = l; }
+        if (vv[q] > mx[q]) { mx[q] = vv[q]; amx[q] = l; }
+      }
+    }
+  // tree merge over row groups through LDS: layout [grp][sub][q][7]
+  float* slot = sm + ((grp * lpr + sub) * 4) * 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float* s = slot + q * 7;
+    s[0] = mo[q].n; s[1] = mo[q].mean; s[2] = mo[q].m2; s[3] = mn[q]; s[4] = mx[q];
+    s[5] = __int_as_float(amn[q]); s[6] = __int_as_float(amx[q]);
+  }
+  for (int stride = groups / 2; stride > 0; stride >>= 1) {
+    __syncthreads();
+    if (grp < stride) {
+      const float* o = sm + (((grp + stride) * lpr + sub) * 4) * 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* s = slot + q * 7; const float* t = o + q * 7;
+        Moments a = {s[0], s[1], s[2]}; const Moments bb = {t[0], t[1], t[2]};
+        mom_merge(a, bb); s[0] = a.n; s[1] = a.mean; s[2] = a.m2;
+        const int ia = __float_as_int(s[5]), ib = __float_as_int(t[5]);
+        if (t[3] < s[3] || (t[3] == s[3] && ib < ia)) { s[3] = t[3]; s[5] = t[5]; }
+        const int ja = __float_as_int(s[6]), jb = __float_as_int(t[6]);
+        if (t[4] > s[4] || (t[4] == s[4] && jb < ja)) { s[4] = t[4]; s[6] = t[6]; }
+      }
+    }
+  }
+  if (grp == 0 && active) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* s = slot + q * 7;
+      float* o = stats + (int64_t)b * 4 * D;
+      o[c + q] = s[1]; o[D + c + q] = s[3]; o[2 * D + c + q] = s[4];
+      o[3 * D + c + q] = sqrtf(s[2] / (s[0] - 1.f));
+      arg[((int64_t)b * 2 + 0) * D + c + q] = __float_as_int(s[5]);
+      arg[((int64_t)b * 2 + 1) * D + c + q] = __float_as_int(s[6]);
+    }
+  }
+}
+
+// dx[b,l,c] (+)= dmean/L + dstd*(x-mean)/((L-1)*std) [0 if std==0] + [l==argmin]*dmin + [l==argmax]*dmax
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const int* __restrict__ arg, const float* __restrict__ dstats,
+                                                       float* __restrict__ dx, int L, int D, int accumulate) {
+  const int d4 = D / 4;
+  const int64_t total = (int64_t)gridDim.y * L * d4;    // gridDim.y = bs
+  const int b = blockIdx.y;
+  const float invL = 1.f / L;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)L * d4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e / d4), c = (int)(e % d4) * 4;
+    const int64_t off = ((int64_t)b * L + l) * D + c;
+    const float4 v = ld4(x + off);
+    const float* st = stats + (int64_t)b * 4 * D; const float* ds = dstats + (int64_t)b * 4 * D;
+    const float4 mean = ld4(st + c), sd = ld4(st + 3 * D + c);
+    const float4 dmean = ld4(ds + c), dmin = ld4(ds + D + c), dmax = ld4(ds + 2 * D + c), dsd = ld4(ds + 3 * D + c);
+    const int4 amn = *reinterpret_cast<const int4*>(arg + ((int64_t)b * 2 + 0) * D + c);
+    const int4 amx = *reinterpret_cast<const int4*>(arg + ((int64_t)b * 2 + 1) * D + c);
+    float4 o;
+    const float k = 1.f / (L - 1.f);
+    o.x = dmean.x * invL + (sd.x > 0.f ? dsd.x * (v.x - mean.x) * k / sd.x : 0.f) + (l == amn.x ? dmin.x : 0.f) + (l == amx.x ? dmax.x : 0.f);
+    o.y = dmean.y * invL + (sd.y > 0.f ? dsd.y * (v.y - mean.y) * k / sd.y : 0.f) + (l == amn.y ? dmin.y : 0.f) + (l == amx.y ? dmax.y : 0.f);
+    o.z = dmean.z * invL + (sd.z > 0.f ? dsd.z * (v.z - mean.z) * k / sd.z : 0.f) + (l == amn.z ? dmin.z : 0.f) + (l == amx.z ? dmax.z : 0.f);
+    o.w = dmean.w * invL + (sd.w > 0.f ? dsd.w * (v.w - mean.w) * k / sd.w : 0.f) + (l == amn.w ? dmin.w : 0.f) + (l == amx.w ? dmax.w : 0.f);
+    if (accumulate) { const float4 p = ld4(dx + off); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    st4(dx + off, o);
+  }
+  (void)total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b,i,j,:] = 0.5 * (x[b,i,j,:] + x[b,j,i,:] (+ s[b,i,j,:D] + s[b,j,i,:D])) * em(b,i,j) * (zero_diag ? i != j : 1)
+// `s` (optional) has row stride lds and contributes its first D features.  One block per (b,i) row of pairs.
+template <int VEC>
+__global__ __launch_bounds__(256) void sym_mask_kernel(const float* __restrict__ x, const float* __restrict__ s, int lds,
+                                                       const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                                       int n, int D, int zero_diag) {
+  const int64_t bi = blockIdx.x;
+  const int64_t b = bi / n; const int i = (int)(bi - b * n);
+  const bool row_ok = mask[bi] != 0;
+  const int dv = D / VEC;
+  for (int t = threadIdx.x; t < n * dv; t += 256) {
+    const int j = t / dv, c = (t - j * dv) * VEC;
+    const int64_t p = bi * n + j, pt = (b * n + j) * n + i;
+    const bool keep = row_ok && mask[b * n + j] && !(zero_diag && i == j);
+    if (VEC == 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (keep) {
+        const float4 a = ld4(x + p * D + c), bb = ld4(x + pt * D + c);
+        v = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+        if (s) {
+          const float* s1 = s + p * lds + c; const float* s2 = s + pt * lds + c;
+          v.x += s1[0] + s2[0]; v.y += s1[1] + s2[1]; v.z += s1[2] + s2[2]; v.w += s1[3] + s2[3];
+        }
+        v.x *= 0.5f; v.y *= 0.5f; v.z *= 0.5f; v.w *= 0.5f;
+      }
+      st4(out + p * D + c, v);
+    } else {
+      float v = 0.f;
+      if (keep) {
+        v = x[p * D + c] + x[pt * D + c];
+        if (s) v += s[p * lds + c] + s[pt * lds + c];
+        v *= 0.5f;
+      }
+      out[p * D + c] = v;
+    }
+  }
+}
+
+// Generic (any D) residual + LayerNorm: one wave per row, scalar accesses.  Slow path for odd widths.
+__global__ __launch_bounds__(256) void ln_res_fwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ y, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out, int64_t rows, int D, float eps,
+                                                                 float drop_p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    auto zval = [&](int c) {
+      const int64_t off = row * D + c;
+      float z = x[off];
+      if (r) z += r[off] * mbvae_drop_scale(drop_p, seed, off);
+      return z;
+    };
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += zval(c);
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = zval(c) - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    for (int c = lane; c < D; c += 64) y[row * D + c] = (zval(c) - mean) * rstd * gamma[c] + beta[c];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  }
+}
+
+// Generic backward; dgamma/dbeta accumulate with float atomics into zeroed buffers (odd widths only occur on
+// small [batch, D] tensors).
+__global__ __launch_bounds__(256) void ln_res_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                 const float* __restrict__ rstd_in, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, float* __restrict__ dr,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 int64_t rows, int D, float drop_p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    auto xhat = [&](int c) {
+      const int64_t off = row * D + c;
+      float z = x[off];
+      if (r) z += r[off] * mbvae_drop_scale(drop_p, seed, off);
+      return (z - mean) * rstd;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < D; c += 64) { const float g = dy[row * D + c] * gamma[c]; s1 += g; s2 += g * xhat(c); }
+    const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+    for (int c = lane; c < D; c += 64) {
+      const int64_t off = row * D + c;
+      const float d = dy[off], xh = xhat(c);
+      const float dz = rstd * (d * gamma[c] - m1 - xh * m2);
+      dx[off] = dz;
+      if (dr) dr[off] = dz * mbvae_drop_scale(drop_p, seed, off);
+      atomicAdd(&dgamma[c], d * xh);
+      atomicAdd(&dbeta[c], d);
+    }
+  }
+}
+
+extern "C" {
+
+// y = LayerNorm(x + dropout_p(r)) * gamma + beta over the last dim D; r may be null.  Saves mean/rstd [rows].
+int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                          float* mean, float* rstd, int64_t rows, int64_t D, float eps, float drop_p, uint64_t seed,
+                          hipStream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return MBVAE_EINVAL;
+  int st = ln_dispatch(true, D, x, r, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                       rows, eps, drop_p, seed, stream);
+  if (st != MBVAE_EUNSUPPORTED) return st;
+  if (D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const int64_t blocks = std::min<int64_t>((rows + 3) / 4, 4096);
+  hipLaunchKernelGGL(ln_res_fwd_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, beta, y, mean,
+                     rstd, rows, (int)D, eps, drop_p, seed);
+  return mbvae_launch_status();
+}
+
+// Gradients of the above: dx (wrt x), dr (wrt r, may be null), dgamma, dbeta [D].
+// workspace: at least mbvae_ln_residual_bwd_workspace(D) bytes.
+int64_t mbvae_ln_residual_bwd_workspace(int64_t D) { return (int64_t)sizeof(float) * (1024 * 2 * D + 2 * D); }
+
+int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,
+                          const float* dy, float* dx, float* dr, float* dgamma, float* dbeta, int64_t rows, int64_t D,
+                          float drop_p, uint64_t seed, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (!x || !gamma || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0) return MBVAE_EINVAL;
+  const int64_t floats = ws_bytes / (int64_t)sizeof(float) - 2 * D;
+  if (floats < 2 * D) return MBVAE_EINVAL;
+  int st = ln_dispatch(false, D, x, r, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx,
+                       dr, dgamma, dbeta, (float*)workspace, floats, rows, 0.f, drop_p, seed, stream);
+  if (st != MBVAE_EUNSUPPORTED) return st;
+  if (D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  if (hipMemsetAsync(dbeta, 0, sizeof(float) * D, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  const int64_t blocks = std::min<int64_t>((rows + 3) / 4, 1024);
+  hipLaunchKernelGGL(ln_res_bwd_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean, rstd, dy,
+                     dx, dr, dgamma, dbeta, rows, (int)D, drop_p, seed);
+  return mbvae_launch_status();
+}
+
+// x [bs,L,D] -> stats [bs,4D] (mean|min|max|std), arg [bs,2,D] int32 (first argmin / argmax along L)
+int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs, int64_t L, int64_t D, hipStream_t stream) {
+  if (!x || !stats || !arg || bs <= 0 || L <= 0 || D <= 0) return MBVAE_EINVAL;
+  if ((D & 3) || bs > 65535 || L > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const int lpr = (int)(D / 4 < 64 ? D / 4 : 64);
+  if (lpr & (lpr - 1)) return MBVAE_EUNSUPPORTED;     // D/4 must be a power of two (or D >= 256 and D % 256 == 0)
+  if (D > 256 && (D % 256)) return MBVAE_EUNSUPPORTED;
+  const size_t smem = (size_t)512 * 4 * 7 * sizeof(float);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)bs), dim3(512), smem, stream, x, stats,
+                     (int*)arg, (int)L, (int)D);
+  return mbvae_launch_status();
+}
+
+int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg, const float* dstats, float* dx,
+                         int64_t bs, int64_t L, int64_t D, int accumulate, hipStream_t stream) {
+  if (!x || !stats || !arg || !dstats || !dx || bs <= 0 || L <= 0 || D <= 0) return MBVAE_EINVAL;
+  if ((D & 3) || bs > 65535) return MBVAE_EUNSUPPORTED;
+  int64_t blocks = (L * (D / 4) + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)blocks, (unsigned)bs), dim3(256), 0, stream, x, stats, (const int*)arg,
+                     dstats, dx, (int)L, (int)D, accumulate);
+  return mbvae_launch_status();
+}
+
+// x [bs,n,n,D] (+ optional skip s [bs,n,n,lds] using its first D features) -> out [bs,n,n,D]
+int mbvae_sym_mask(const float* x, const float* s, int64_t lds, const uint8_t* mask, float* out, int64_t bs, int64_t n,
+                   int64_t D, int zero_diag, hipStream_t stream) {
+  if (!x || !mask || !out || bs <= 0 || n <= 0 || D <= 0 || x == out) return MBVAE_EINVAL;
+  if (bs * n > 0x7fffffff || n * D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const bool vec = (D % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0);
+  if (vec) hipLaunchKernelGGL(sym_mask_kernel<4>, dim3((unsigned)(bs * n)), dim3(256), 0, stream, x, s, (int)lds, mask, out,
+                              (int)n, (int)D, zero_diag);
+  else hipLaunchKernelGGL(sym_mask_kernel<1>, dim3((unsigned)(bs * n)), dim3(256), 0, stream, x, s, (int)lds, mask, out,
+                          (int)n, (int)D, zero_diag);
+  return mbvae_launch_status();
+}
+
+}  // extern "C"

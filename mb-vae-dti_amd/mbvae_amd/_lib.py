@@ -1,0 +1,67 @@
+"""ctypes binding of libmbvae_hip.so (the C ABI declared in include/mbvae_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing, or a kernel
+entry point returns a non-zero status, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmbvae_hip.so")
+
+_P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
+
+# name -> argtypes (restype is int unless listed in _RET64)
+SIGNATURES = {
+    "mbvae_linear_fwd": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P, _I, _I, _F, _U, _I, _P, _L, _P],
+    "mbvae_linear_bwd_input": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
+    "mbvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
+    "mbvae_edge_attn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
+    "mbvae_edge_attn_bwd": [_P] * 18 + [_L, _L, _L, _F, _P],
+    "mbvae_ln_residual_fwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P],
+    "mbvae_ln_residual_bwd_workspace": [_L],
+    "mbvae_ln_residual_bwd": [_P] * 10 + [_L, _L, _F, _U, _P, _L, _P],
+    "mbvae_pool_stats_fwd": [_P, _P, _P, _L, _L, _L, _P],
+    "mbvae_pool_stats_bwd": [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P],
+    "mbvae_sym_mask": [_P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
+    "mbvae_masked_ce_workspace": [],
+    "mbvae_masked_ce_fwd": [_P, _P, _P, _L, _L, _P, _L, _P],
+    "mbvae_masked_ce_bwd": [_P, _P, _P, _P, _L, _L, _P],
+    "mbvae_kl_workspace": [],
+    "mbvae_kl_reparam_fwd": [_P, _P, _P, _P, _P, _L, _P, _L, _P],
+    "mbvae_kl_reparam_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "mbvae_apply_noise": [_P] * 12 + [_L, _L, _L, _L, _P],
+    "mbvae_reverse_sample": [_P] * 18 + [_L, _L, _L, _L, _P],
+}
+_RET64 = {"mbvae_ln_residual_bwd_workspace", "mbvae_masked_ce_workspace", "mbvae_kl_workspace"}
+
+_STATUS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it has not been built (python mb-vae-dti_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first (python mb-vae-dti_amd/build.py). "
+                           "There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int64 if name in _RET64 else c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    st = getattr(load(), name)(*args)
+    if st != 0:
+        raise RuntimeError(f"{name} failed: {_STATUS.get(st, st)}")
+
+
+def query(name, *args):
+    return int(getattr(load(), name)(*args))

@@ -1,0 +1,154 @@
+"""Graph-transformer denoiser on the HIP kernels; drop-in for the reference module.
+
+Same constructor, parameter names (state_dict keys) and forward contract as
+mb_vae_dti/training/models/graph_transformer.py:70-343 (Xtoy, Etoy, XEyTransformerLayer, NodeEdgeBlock,
+GraphTransformer).  Parameters live in ordinary nn.Linear / nn.LayerNorm containers and are read in place
+by the kernels, so checkpoints load unchanged.  The reference's host-synchronising assert_* checks are dropped.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .containers import PlaceHolder
+
+
+class _SeedStream:
+    """Per-forward stream of dropout seeds derived from torch's CPU generator (no device sync)."""
+
+    def __init__(self, active):
+        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if active else 0
+        self.k = 0
+
+    def next(self):
+        self.k += 1
+        return self.base * 4096 + self.k
+
+
+def _lin(layer, x, **kw):
+    return ops.linear(x, layer.weight, layer.bias, **kw)
+
+
+class Xtoy(nn.Module):
+    def __init__(self, dx, dy):
+        super().__init__()
+        self.lin = nn.Linear(4 * dx, dy)
+
+    def forward(self, X):
+        return _lin(self.lin, ops.pool_stats(X))
+
+
+class Etoy(nn.Module):
+    def __init__(self, d, dy):
+        super().__init__()
+        self.lin = nn.Linear(4 * d, dy)
+
+    def forward(self, E):
+        return _lin(self.lin, ops.pool_stats(E))
+
+
+class NodeEdgeBlock(nn.Module):
+    """Self-attention block that also updates the edge and global representations."""
+
+    def __init__(self, dx, de, dy, n_head, **kwargs):
+        super().__init__()
+        assert dx % n_head == 0, f"dx: {dx} -- nhead: {n_head}"
+        self.dx, self.de, self.dy, self.df, self.n_head = dx, de, dy, dx // n_head, n_head
+        self.q, self.k, self.v = nn.Linear(dx, dx), nn.Linear(dx, dx), nn.Linear(dx, dx)
+        self.e_add, self.e_mul = nn.Linear(de, dx), nn.Linear(de, dx)
+        self.y_e_mul, self.y_e_add = nn.Linear(dy, dx), nn.Linear(dy, dx)
+        self.y_x_mul, self.y_x_add = nn.Linear(dy, dx), nn.Linear(dy, dx)
+        self.y_y = nn.Linear(dy, dy)
+        self.x_y, self.e_y = Xtoy(dx, dy), Etoy(de, dy)
+        self.x_out, self.e_out = nn.Linear(dx, dx), nn.Linear(dx, de)
+        self.y_out = nn.Sequential(nn.Linear(dy, dy), nn.ReLU(), nn.Linear(dy, dy))
+
+    def forward(self, X, E, y, node_mask):
+        n = X.shape[1]
+        node = dict(mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
+        edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
+        Q, K, V = _lin(self.q, X, **node), _lin(self.k, X, **node), _lin(self.v, X, **node)
+        E1, E2 = _lin(self.e_mul, E, **edge), _lin(self.e_add, E, **edge)
+        P, wV = ops.edge_attention(Q, K, V, E1, E2, _lin(self.y_e_add, y), _lin(self.y_e_mul, y), node_mask, self.n_head)
+        newE = _lin(self.e_out, P, **edge)
+        newX = _lin(self.x_out, _lin(self.y_x_add, y).unsqueeze(1) + (_lin(self.y_x_mul, y).unsqueeze(1) + 1) * wV, **node)
+        new_y = _lin(self.y_y, y) + self.x_y(X) + self.e_y(E)
+        new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
+        return newX, newE, new_y
+
+
+class XEyTransformerLayer(nn.Module):
+    """Updates node, edge and global features (attention block + three residual feed-forward blocks)."""
+
+    def __init__(self, dx, de, dy, n_head, dim_ffX=2048, dim_ffE=128, dim_ffy=2048, dropout=0.1,
+                 layer_norm_eps=1e-5, device=None, dtype=None):
+        super().__init__()
+        kw = {"device": device, "dtype": dtype}
+        self.self_attn = NodeEdgeBlock(dx, de, dy, n_head)
+        self.linX1, self.linX2 = nn.Linear(dx, dim_ffX, **kw), nn.Linear(dim_ffX, dx, **kw)
+        self.normX1, self.normX2 = nn.LayerNorm(dx, eps=layer_norm_eps, **kw), nn.LayerNorm(dx, eps=layer_norm_eps, **kw)
+        self.linE1, self.linE2 = nn.Linear(de, dim_ffE, **kw), nn.Linear(dim_ffE, de, **kw)
+        self.normE1, self.normE2 = nn.LayerNorm(de, eps=layer_norm_eps, **kw), nn.LayerNorm(de, eps=layer_norm_eps, **kw)
+        self.lin_y1, self.lin_y2 = nn.Linear(dy, dim_ffy, **kw), nn.Linear(dim_ffy, dy, **kw)
+        self.norm_y1, self.norm_y2 = nn.LayerNorm(dy, eps=layer_norm_eps, **kw), nn.LayerNorm(dy, eps=layer_norm_eps, **kw)
+        self.dropout_p = dropout
+        self.eps = layer_norm_eps
+
+    def forward(self, X, E, y, node_mask, seeds=None):
+        p = self.dropout_p if self.training else 0.0
+        seeds = seeds or _SeedStream(p > 0)
+        newX, newE, new_y = self.self_attn(X, E, y, node_mask)
+
+        def norm(ln, x, r):
+            return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
+
+        X, E, y = norm(self.normX1, X, newX), norm(self.normE1, E, newE), norm(self.norm_y1, y, new_y)
+
+        def ff(l1, l2, x):
+            return _lin(l2, _lin(l1, x, act=1, drop_p=p, seed=seeds.next()))
+
+        X = norm(self.normX2, X, ff(self.linX1, self.linX2, X))
+        E = norm(self.normE2, E, ff(self.linE1, self.linE2, E))
+        y = norm(self.norm_y2, y, ff(self.lin_y1, self.lin_y2, y))
+        return X, E, y
+
+
+class GraphTransformer(nn.Module):
+    """n_layers x XEyTransformerLayer between input and output MLPs; returns a masked PlaceHolder(X, E, y)."""
+
+    def __init__(self, n_layers, input_dims, hidden_mlp_dims, hidden_dims, output_dims, act_fn_in=None, act_fn_out=None):
+        super().__init__()
+        for fn in (act_fn_in, act_fn_out):
+            if fn is not None and not isinstance(fn, nn.ReLU):
+                raise ValueError("only ReLU activations are implemented in the HIP path (the reference uses ReLU)")
+        self.n_layers = n_layers
+        self.out_dim_X, self.out_dim_E, self.out_dim_y = output_dims["X"], output_dims["E"], output_dims["y"]
+        h, hm = hidden_dims, hidden_mlp_dims
+        relu = nn.ReLU
+        self.mlp_in_X = nn.Sequential(nn.Linear(input_dims["X"], hm["X"]), relu(), nn.Linear(hm["X"], h["dx"]), relu())
+        self.mlp_in_E = nn.Sequential(nn.Linear(input_dims["E"], hm["E"]), relu(), nn.Linear(hm["E"], h["de"]), relu())
+        self.mlp_in_y = nn.Sequential(nn.Linear(input_dims["y"], hm["y"]), relu(), nn.Linear(hm["y"], h["dy"]), relu())
+        self.tf_layers = nn.ModuleList([
+            XEyTransformerLayer(dx=h["dx"], de=h["de"], dy=h["dy"], n_head=h["n_head"], dim_ffX=h["dim_ffX"],
+                                dim_ffE=h["dim_ffE"], dim_ffy=h["dim_ffy"]) for _ in range(n_layers)])
+        self.mlp_out_X = nn.Sequential(nn.Linear(h["dx"], hm["X"]), relu(), nn.Linear(hm["X"], output_dims["X"]))
+        self.mlp_out_E = nn.Sequential(nn.Linear(h["de"], hm["E"]), relu(), nn.Linear(hm["E"], output_dims["E"]))
+        self.mlp_out_y = nn.Sequential(nn.Linear(h["dy"], hm["y"]), relu(), nn.Linear(hm["y"], output_dims["y"]))
+
+    def forward(self, X, E, y, node_mask):
+        n = X.shape[1]
+        X, E, y = X.float(), E.float(), y.float()
+        xm = node_mask.unsqueeze(-1).to(X.dtype)
+        seeds = _SeedStream(self.training)
+
+        def mlp(seq, t, last_act, **kw):
+            return _lin(seq[2], _lin(seq[0], t, act=1), act=1 if last_act else 0, **kw)
+
+        hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
+        hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
+        hy = mlp(self.mlp_in_y, y, True)
+        for layer in self.tf_layers:
+            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds)
+        oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
+        oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
+        oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]
+        return PlaceHolder(X=oX, E=oE, y=oy)

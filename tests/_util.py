@@ -1,0 +1,34 @@
+"""Helpers shared by the tests: fixture loading and the parity comparison."""
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    """Fixture file -> dict of torch tensors; keys 'a/b' become nested dicts {'a': {'b': ...}}."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        v = z[k]
+        t = torch.from_numpy(v) if v.dtype.kind in "fiub" else v
+        if "/" in k:
+            a, b = k.split("/", 1)
+            out.setdefault(a, {})[b] = t
+        else:
+            out[k] = t
+    return out
+
+
+def assert_close(a, b, rtol=1e-5, atol=None, what=""):
+    """max |a-b| <= rtol * max(1, max|b|)  (relative to the tensor's scale, as the parity bar is stated)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    tol = rtol * scale if atol is None else atol
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"

@@ -1,0 +1,342 @@
+"""GPU parity: every HIP kernel, through the C ABI, against the CPU oracle and the golden fixtures.
+
+Tolerance: fp32 results within 1e-5 of the tensor's scale (max|ref|, at least 1); class ids, masks and
+one-hot samples bit-exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests._util import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda() if torch.is_tensor(t) else t
+
+
+def ragged_mask(bs, n, gen):
+    sizes = torch.randint(1, n + 1, (bs,), generator=gen)
+    sizes[0] = n
+    return torch.arange(n)[None, :] < sizes[:, None]
+
+
+# ------------------------------------------------------------------------------------------------ linear
+@pytest.mark.parametrize("M,K,N,act,mode", [
+    (300, 64, 256, 0, "none"), (1000, 5, 128, 1, "none"), (4 * 9, 13, 24, 1, "node"), (4 * 81, 16, 32, 0, "edge"),
+    (2 * 64 * 64, 256, 64, 0, "edge"), (256, 1037, 2048, 1, "none"), (256, 1024, 1024, 0, "none"), (70, 128, 5, 0, "none"),
+    (5000, 64, 128, 1, "none"), (33, 4170, 512, 0, "none"),
+])
+def test_linear_fwd_bwd(ops, M, K, N, act, mode):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    cot = torch.randn(M, N, generator=g)
+    mask, n, mm = None, 0, ops.MASK_NONE
+    keep = torch.ones(M, 1)
+    if mode == "node":
+        n = 9; mask = ragged_mask(M // n, n, g); mm = ops.MASK_NODE; keep = mask.reshape(M, 1).float()
+    elif mode == "edge":
+        n = int(round(math.sqrt(M // (4 if M == 4 * 81 else 2)))); bs = M // (n * n)
+        mask = ragged_mask(bs, n, g); mm = ops.MASK_EDGE
+        keep = (mask.unsqueeze(1) & mask.unsqueeze(2)).reshape(M, 1).float()
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y = F.linear(xr, wr, br)
+    y = (F.relu(y) if act else y) * keep
+    (y * cot).sum().backward()
+    xg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    yg = ops.linear(xg, wg, bg, act=act, mask=dev(mask), mask_mode=mm, n_nodes=n)
+    (yg * cot.cuda()).sum().backward()
+    assert_close(yg, y, what="y")
+    assert_close(xg.grad, xr.grad, what="dx")
+    assert_close(wg.grad, wr.grad, rtol=2e-5, what="dw")
+    assert_close(bg.grad, br.grad, rtol=2e-5, what="db")
+
+
+def test_linear_relu_dropout_statistics(ops):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4096, 64, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(128, 64, generator=g) / 8).cuda().requires_grad_(True)
+    b = torch.zeros(128).cuda().requires_grad_(True)
+    y0 = ops.linear(x, w, b, act=1)
+    y1 = ops.linear(x, w, b, act=1, drop_p=0.25, seed=1234)
+    y2 = ops.linear(x, w, b, act=1, drop_p=0.25, seed=1234)
+    assert torch.equal(y1, y2)                                   # same seed -> same mask
+    pos = y0 > 0
+    kept = (y1 > 0) & pos
+    frac = kept.sum().item() / pos.sum().item()
+    assert abs(frac - 0.75) < 0.01
+    assert_close(y1[kept], y0[kept] / 0.75, what="kept values scaled by 1/(1-p)")
+    # backward uses the saved post-dropout activation as the gate
+    y1.sum().backward()
+    gx = x.grad.clone(); x.grad = None
+    (y0 * kept.float() / 0.75).sum().backward()
+    assert_close(gx, x.grad, what="dropout backward")
+
+
+# ------------------------------------------------------------------------------------------------ edge attention
+@pytest.mark.parametrize("bs,n,dx,H", [(4, 9, 32, 4), (2, 64, 256, 8), (3, 17, 64, 4), (2, 70, 32, 2)])
+def test_edge_attention(ops, bs, n, dx, H):
+    from oracle import denoiser as O
+    g = torch.Generator().manual_seed(bs * n + dx)
+    mask = ragged_mask(bs, n, g)
+    xm = mask.unsqueeze(-1).float(); em = xm.unsqueeze(2) * xm.unsqueeze(1)
+    Q, K, V = (torch.randn(bs, n, dx, generator=g) * xm for _ in range(3))
+    E1, E2 = (torch.randn(bs, n, n, dx, generator=g) * 0.5 * em for _ in range(2))
+    ya, ym = torch.randn(bs, dx, generator=g), torch.randn(bs, dx, generator=g) * 0.3
+    cP, cW = torch.randn(bs, n, n, dx, generator=g), torch.randn(bs, n, dx, generator=g)
+    cpu = [t.clone().requires_grad_(True) for t in (Q, K, V, E1, E2, ya, ym)]
+    P, wV = O.edge_attention(*cpu, mask, H)
+    ((P * cP).sum() + (wV * cW).sum()).backward()
+    gpu = [t.clone().cuda().requires_grad_(True) for t in (Q, K, V, E1, E2, ya, ym)]
+    Pg, wVg = ops.edge_attention(*gpu, mask.cuda(), H)
+    ((Pg * cP.cuda()).sum() + (wVg * cW.cuda()).sum()).backward()
+    assert_close(Pg, P, what="P"); assert_close(wVg, wV, what="wV")
+    for name, a, b in zip(("dQ", "dK", "dV", "dE1", "dE2", "dye_add", "dye_mul"), gpu, cpu):
+        assert_close(a.grad, b.grad, rtol=2e-5, what=name)
+
+
+# ------------------------------------------------------------------------------------------------ residual + LayerNorm
+@pytest.mark.parametrize("rows,D", [(4 * 81, 16), (1000, 64), (300, 256), (256, 1024), (77, 32), (50, 2048), (64, 24), (10, 48)])
+def test_ln_residual(ops, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x, r = torch.randn(rows, D, generator=g) * 2 + 0.5, torch.randn(rows, D, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    cot = torch.randn(rows, D, generator=g)
+    c = [t.clone().requires_grad_(True) for t in (x, r, gamma, beta)]
+    y = F.layer_norm(c[0] + c[1], (D,), c[2], c[3], 1e-5)
+    (y * cot).sum().backward()
+    q = [t.clone().cuda().requires_grad_(True) for t in (x, r, gamma, beta)]
+    yg = ops.ln_residual(q[0], q[1], q[2], q[3], 1e-5)
+    (yg * cot.cuda()).sum().backward()
+    assert_close(yg, y, what="y")
+    for name, a, b in zip(("dx", "dr", "dgamma", "dbeta"), q, c):
+        assert_close(a.grad, b.grad, rtol=2e-5, what=name)
+    # r = None path
+    y2 = ops.ln_residual(q[0].detach(), None, q[2].detach(), q[3].detach(), 1e-5)
+    assert_close(y2, F.layer_norm(x, (D,), gamma, beta, 1e-5), what="plain LN")
+
+
+def test_ln_residual_dropout_consistent(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(512, 64, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(512, 64, generator=g).cuda().requires_grad_(True)
+    gamma, beta = torch.ones(64).cuda().requires_grad_(True), torch.zeros(64).cuda().requires_grad_(True)
+    y = ops.ln_residual(x, r, gamma, beta, 1e-5, 0.3, 77)
+    y.pow(2).sum().backward()
+    # LayerNorm output is invariant to the scale, so a dropped element shows up as zero gradient on r
+    dropped = (r.grad == 0)
+    frac = dropped.float().mean().item()
+    assert abs(frac - 0.3) < 0.02
+    kept = ~dropped
+    assert_close(r.grad[kept], x.grad[kept] / 0.7, rtol=1e-5, what="dr = dz/(1-p) on kept elements")
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+@pytest.mark.parametrize("shape", [(4, 9, 32), (4, 9, 9, 16), (3, 64, 256), (2, 64, 64, 64), (5, 7, 7, 8)])
+def test_pool_stats(ops, shape):
+    from oracle import denoiser as O
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    x[0, 0] = 0                               # padded-looking rows stay in the statistics
+    dims = tuple(range(1, len(shape) - 1))
+    cot = torch.randn(shape[0], 4 * shape[-1], generator=g)
+    xr = x.clone().requires_grad_(True)
+    s = O.pool_stats(xr, dims)
+    (s * cot).sum().backward()
+    xg = x.clone().cuda().requires_grad_(True)
+    sg = ops.pool_stats(xg)
+    (sg * cot.cuda()).sum().backward()
+    assert_close(sg, s, what="stats")
+    assert_close(xg.grad, xr.grad, rtol=2e-5, what="dx")
+
+
+# ------------------------------------------------------------------------------------------------ symmetrise + mask
+@pytest.mark.parametrize("D,zero_diag,skip_w", [(16, False, 0), (5, True, 5), (64, False, 0), (5, True, 13)])
+def test_sym_mask(ops, D, zero_diag, skip_w):
+    g = torch.Generator().manual_seed(D)
+    bs, n = 3, 11
+    mask = ragged_mask(bs, n, g)
+    x = torch.randn(bs, n, n, D, generator=g)
+    skip = torch.randn(bs, n, n, skip_w, generator=g) if skip_w else None
+    em = (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1).float()
+    od = (~torch.eye(n, dtype=torch.bool))[None, :, :, None].float() if zero_diag else 1.0
+    xr = x.clone().requires_grad_(True)
+    t = xr + skip[..., :D] if skip is not None else xr
+    t = t * od
+    ref = 0.5 * (t + t.transpose(1, 2)) * em
+    cot = torch.randn(bs, n, n, D, generator=g)
+    (ref * cot).sum().backward()
+    xg = x.clone().cuda().requires_grad_(True)
+    out = ops.sym_mask(xg, mask.cuda(), skip=dev(skip), zero_diag=zero_diag)
+    (out * cot.cuda()).sum().backward()
+    assert_close(out, ref, what="sym"); assert_close(xg.grad, xr.grad, what="d sym")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_masked_ce_golden(ops):
+    g = load_golden("heads")
+    pX, pE = g["rc_pred_X"].cuda().requires_grad_(True), g["rc_pred_E"].cuda().requires_grad_(True)
+    lX, sX = ops.masked_ce(pX, g["rc_true_X"].cuda())
+    lE, sE = ops.masked_ce(pE, g["rc_true_E"].cuda())
+    loss = lX * 1 + lE * 5
+    loss.backward()
+    assert_close(loss, g["rc_loss"], what="loss")
+    assert_close(pX.grad, g["rc_dX"], what="dX"); assert_close(pE.grad, g["rc_dE"], what="dE")
+    assert_close(sE[2:7] / sE[1], g["rc_bce_E"], what="per-class BCE E")
+    assert_close(sX[2:10] / sX[1], g["rc_bce_X"], what="per-class BCE X")
+
+
+def test_masked_ce_large(ops):
+    from oracle import heads as OH
+    g = torch.Generator().manual_seed(9)
+    R, C = 200_000, 5
+    logits = torch.randn(R, C, generator=g) * 3
+    cls = torch.randint(0, C, (R,), generator=g)
+    tgt = F.one_hot(cls, C).float() * (torch.rand(R, 1, generator=g) < 0.8)
+    lr = logits.clone().requires_grad_(True)
+    ref = OH.reconstruction_loss(lr[:1], lr, tgt[:1], tgt, [0, 1]); ref.backward()
+    lg = logits.clone().cuda().requires_grad_(True)
+    out, _ = ops.masked_ce(lg, tgt.cuda()); out.backward()
+    assert_close(out, ref, what="ce"); assert_close(lg.grad, lr.grad, atol=1e-9, what="dlogits")
+
+
+def test_kl_reparam_golden(ops):
+    g = load_golden("heads")
+    mu, lv = g["kl_mu"].cuda().requires_grad_(True), g["kl_logvar"].cuda().requires_grad_(True)
+    z, kl = ops.kl_reparam(mu, lv, g["kl_eps"].cuda())
+    assert_close(z, g["kl_z"], what="z"); assert_close(kl, g["kl_value"], what="kl")
+    cot = torch.randn(z.shape, generator=torch.Generator().manual_seed(1))
+    ((z * cot.cuda()).sum() + 3 * kl).backward()
+    mr, lr = g["kl_mu"].clone().requires_grad_(True), g["kl_logvar"].clone().requires_grad_(True)
+    from oracle import heads as OH
+    zr = mr + g["kl_eps"] * torch.exp(0.5 * lr)
+    ((zr * cot).sum() + 3 * OH.kl_divergence(mr, lr)).backward()
+    assert_close(mu.grad, mr.grad, what="dmu"); assert_close(lv.grad, lr.grad, what="dlogvar")
+
+
+# ------------------------------------------------------------------------------------------------ diffusion samplers
+def test_apply_noise_bit_exact_golden(ops):
+    g = load_golden("noise")
+    mask = g["mask"].bool().cuda()
+    for mode in ("train", "eval"):
+        Xc, Ec, Xt, Et = ops.apply_noise(g["X"].cuda(), g["E"].cuda(), mask, g[f"{mode}_alpha_t_bar"].cuda(), g["mx"].cuda(),
+                                         g["me"].cuda(), g[f"{mode}_expX"].cuda(), g[f"{mode}_expE"].cuda())
+        assert torch.equal(Xt.cpu(), g[f"{mode}_X_t"]) and torch.equal(Et.cpu(), g[f"{mode}_E_t"])
+        assert torch.equal(Xc.cpu(), g[f"{mode}_Xc"]) and torch.equal(Ec.cpu(), g[f"{mode}_Ec"])
+
+
+def test_apply_noise_bit_exact_large(ops):
+    from oracle import diffusion as OD
+    g = torch.Generator().manual_seed(5)
+    bs, n, cx, ce = 16, 64, 5, 5
+    mask = ragged_mask(bs, n, g)
+    mx = torch.tensor([.72, .12, .10, .04, .02]); me = torch.tensor([.90, .05, .03, .01, .01])
+    Xc0 = torch.multinomial(mx, bs * n, True, generator=g).reshape(bs, n)
+    Ec0 = torch.multinomial(me, bs * n * n, True, generator=g).reshape(bs, n, n)
+    Ec0 = torch.triu(Ec0, 1); Ec0 = Ec0 + Ec0.transpose(1, 2)
+    X0 = F.one_hot(Xc0, cx).float() * mask.unsqueeze(-1)
+    E0 = F.one_hot(Ec0, ce).float(); E0[:, torch.arange(n), torch.arange(n)] = 0
+    sch = OD.Schedule(500)
+    t_int = torch.randint(0, 501, (bs, 1), generator=g).float()
+    eX = torch.empty(bs * n, cx).exponential_(1, generator=g); eE = torch.empty(bs * n * n, ce).exponential_(1, generator=g)
+    Xt, Et, npar, Xc, Ec = OD.apply_noise(sch, mx, me, X0, E0, mask, t_int, eX, eE)
+    gXc, gEc, gXt, gEt = ops.apply_noise(X0.cuda(), E0.cuda(), mask.cuda(), npar["alpha_t_bar"].cuda(), mx.cuda(), me.cuda(),
+                                         eX.cuda(), eE.cuda())
+    assert torch.equal(gXt.cpu(), Xt) and torch.equal(gEt.cpu(), Et)
+    assert torch.equal(gXc.cpu(), Xc) and torch.equal(gEc.cpu(), Ec)
+    assert torch.equal(gEt, gEt.transpose(1, 2))
+
+
+def _flip_ok(prob, cls_gpu, cls_ref, expo):
+    """Samples may differ from the reference only where the two best ratios are within fp32 noise."""
+    bad = cls_gpu != cls_ref
+    if not bad.any():
+        return True
+    ratio = (prob / expo)[bad]
+    top2 = ratio.topk(2, dim=-1).values
+    return bool(((top2[:, 0] - top2[:, 1]) / top2[:, 0] < 1e-4).all())
+
+
+def test_reverse_sample_golden(ops):
+    g = load_golden("reverse_step")
+    from oracle import diffusion as OD
+    sch = OD.Schedule(500)
+    mask = g["mask"].bool()
+    t, s = g["t"], g["s"]
+    beta, a_s, a_t = sch.beta(t_normalized=t), sch.alpha_bar(t_normalized=s), sch.alpha_bar(t_normalized=t)
+    Xc, Ec, Xs, Es, pX, pE = ops.reverse_sample(g["logits_X"].cuda(), g["logits_E"].cuda(), g["X_t"].cuda(), g["E_t"].cuda(),
+                                                mask.cuda(), beta.cuda(), a_s.cuda(), a_t.cuda(), g["mx"].cuda(), g["me"].cuda(),
+                                                g["expX"].cuda(), g["expE"].cuda(), want_probs=True)
+    xm = mask.unsqueeze(-1).float(); em = xm.unsqueeze(2) * xm.unsqueeze(1)
+    assert_close(pX.cpu() * xm, g["prob_X"] * xm, rtol=1e-5, what="prob X")
+    assert_close(pE.cpu() * em, g["prob_E"] * em, rtol=1e-5, what="prob E")
+    assert torch.equal(Xs.cpu(), g["X_s"]) and torch.equal(Es.cpu(), g["E_s"])
+
+
+# ------------------------------------------------------------------------------------------------ whole denoiser
+def _build_denoiser(dims, sd):
+    from mbvae_amd.graph_transformer import GraphTransformer
+    net = GraphTransformer(**dims)
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+def test_denoiser_tiny_forward_backward_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    g = load_golden("denoiser_tiny")
+    dims = dict(n_layers=2, input_dims={"X": 13, "E": 5, "y": 45}, hidden_mlp_dims={"X": 24, "E": 16, "y": 40},
+                hidden_dims={"dx": 32, "de": 16, "dy": 32, "n_head": 4, "dim_ffX": 24, "dim_ffE": 16, "dim_ffy": 40},
+                output_dims={"X": 5, "E": 5, "y": 32})
+    net = _build_denoiser(dims, g["sd"]).eval()
+    X, E, y = (g[k].cuda().requires_grad_(True) for k in ("X", "E", "y"))
+    out = net(X, E, y, g["mask"].bool().cuda())
+    assert_close(out.X, g["out_X"], what="X"); assert_close(out.E, g["out_E"], what="E"); assert_close(out.y, g["out_y"], what="y")
+    ((out.X * g["cX"].cuda()).sum() + (out.E * g["cE"].cuda()).sum() + (out.y * g["cy"].cuda()).sum()).backward()
+    assert_close(X.grad, g["dX"], rtol=2e-5, what="dX"); assert_close(E.grad, g["dE"], rtol=2e-5, what="dE")
+    assert_close(y.grad, g["dy"], rtol=2e-5, what="dy")
+    for k, p in net.named_parameters():
+        assert_close(p.grad, g["grad"][k], rtol=3e-5, what="grad " + k)
+
+
+def test_layer_tiny_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.graph_transformer import XEyTransformerLayer
+    g = load_golden("layer_tiny")
+    layer = XEyTransformerLayer(dx=32, de=16, dy=32, n_head=4, dim_ffX=24, dim_ffE=16, dim_ffy=40)
+    layer.load_state_dict(g["sd"]); layer = layer.cuda().eval()
+    mask = g["mask"].bool().cuda()
+    nX, nE, ny = layer.self_attn(g["X"].cuda(), g["E"].cuda(), g["y"].cuda(), mask)
+    assert_close(nX, g["blk_X"], what="block X"); assert_close(nE, g["blk_E"], what="block E"); assert_close(ny, g["blk_y"], what="block y")
+    X, E, y = layer(g["X"].cuda(), g["E"].cuda(), g["y"].cuda(), mask)
+    assert_close(X, g["out_X"], what="layer X"); assert_close(E, g["out_E"], what="layer E"); assert_close(y, g["out_y"], what="layer y")
+
+
+def test_denoiser_realwidth_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests._weights import synthetic_state_dict
+    g = load_golden("denoiser_realwidth")
+    shapes = {str(k): tuple(int(d) for d in dims if d > 0) for k, dims in zip(g["shape_names"], g["shape_dims"])}
+    dims = dict(n_layers=1, input_dims={"X": 13, "E": 5, "y": 1037}, hidden_mlp_dims={"X": 256, "E": 128, "y": 2048},
+                hidden_dims={"dx": 256, "de": 64, "dy": 1024, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 1024},
+                output_dims={"X": 5, "E": 5, "y": 1024})
+    net = _build_denoiser(dims, synthetic_state_dict(shapes)).eval()
+    with torch.no_grad():
+        out = net(g["X"].cuda(), g["E"].cuda(), g["y"].cuda(), g["mask"].bool().cuda())
+    assert_close(out.X, g["out_X"], what="X"); assert_close(out.E, g["out_E"], what="E")
+    assert_close(out.y, g["out_y"], rtol=2e-5, what="y")
