@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #define MBVAE_OK 0
 #define MBVAE_EINVAL (-1)
@@ -14,7 +15,9 @@
 
 static inline int mbvae_launch_status() {
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? MBVAE_OK : MBVAE_ELAUNCH;
+  if (e == hipSuccess) return MBVAE_OK;
+  fprintf(stderr, "libmbvae_hip: HIP error %d: %s\n", (int)e, hipGetErrorString(e));
+  return MBVAE_ELAUNCH;
 }
 
 // Counter-based uniform in [0,1): splitmix64 of (seed, element index).  Used for dropout so that

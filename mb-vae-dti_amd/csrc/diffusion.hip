@@ -156,6 +156,7 @@ extern "C" {
 int mbvae_apply_noise(const float* X0, const float* E0, const uint8_t* mask, const float* abar_t, const float* mx,
                       const float* me, const float* expX, const float* expE, int64_t* Xc, int64_t* Ec, float* Xt,
                       float* Et, int64_t bs, int64_t n, int64_t cx, int64_t ce, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!X0 || !E0 || !mask || !abar_t || !mx || !me || !expX || !expE || !Xc || !Ec || !Xt || !Et) return MBVAE_EINVAL;
   if (bs <= 0 || n <= 0 || cx <= 0 || ce <= 0 || cx > DF_MAX_C || ce > DF_MAX_C || n > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   const int64_t nodes = bs * n, pairs = bs * n * n;
@@ -171,6 +172,7 @@ int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float
                          const float* beta_t, const float* abar_s, const float* abar_t, const float* mx, const float* me,
                          const float* expX, const float* expE, int64_t* Xc, int64_t* Ec, float* Xs, float* Es,
                          float* probX, float* probE, int64_t bs, int64_t n, int64_t cx, int64_t ce, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!logitsX || !logitsE || !Xt || !Et || !mask || !beta_t || !abar_s || !abar_t || !mx || !me || !expX || !expE ||
       !Xc || !Ec || !Xs || !Es)
     return MBVAE_EINVAL;

@@ -194,6 +194,7 @@ int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, const fl
                         const float* ye_add, const float* ye_mul, const uint8_t* mask,
                         float* P, float* wV, float* lse, int64_t bs, int64_t n, int64_t dx, float scale,
                         hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
   if (bs > 65535 || n > 0x7fffffff / 4) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_add, ye_mul, P, wV, lse};
@@ -212,6 +213,7 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, const fl
                         const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
                         float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
                         float scale, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
   if (bs > 65535 || n > 32 * 65535) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};

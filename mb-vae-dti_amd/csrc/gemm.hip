@@ -335,6 +335,7 @@ extern "C" {
 int mbvae_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
                      int64_t M, int64_t K, int64_t N, int act, const uint8_t* mask, int mask_mode, int n_nodes,
                      float drop_p, uint64_t seed, int accumulate, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
   GemmArgs g = {};
@@ -350,6 +351,7 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
                            int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
                            const uint8_t* mask, int mask_mode, int n_nodes, int accumulate,
                            void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
   if (gate && lddy != N) return MBVAE_EINVAL;     // gate shares dy's layout
@@ -366,6 +368,7 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
                             int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
                             const uint8_t* mask, int mask_mode, int n_nodes, int accumulate,
                             void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
   if (gate && lddy != N) return MBVAE_EINVAL;

@@ -135,6 +135,7 @@ int64_t mbvae_masked_ce_workspace() { return (int64_t)sizeof(float) * 1024 * (2 
 // out[0] = sum of CE over kept rows, out[1] = #kept rows, out[2+c] = sum over kept rows of BCEWithLogits(logit_c, target_c)
 int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, int64_t rows, int64_t C,
                         void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!logits || !target || !out || !workspace || rows <= 0) return MBVAE_EINVAL;
   if (C <= 0 || C > CE_MAX_C) return MBVAE_EUNSUPPORTED;
   if (ws_bytes < mbvae_masked_ce_workspace()) return MBVAE_EINVAL;
@@ -147,6 +148,7 @@ int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, in
 // dlogits = keep * (softmax(logits) - onehot(class)) * coef[0]   (coef on device: lambda * upstream / count)
 int mbvae_masked_ce_bwd(const float* logits, const float* target, const float* coef, float* dlogits, int64_t rows,
                         int64_t C, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!logits || !target || !coef || !dlogits || rows <= 0) return MBVAE_EINVAL;
   if (C <= 0 || C > CE_MAX_C) return MBVAE_EUNSUPPORTED;
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
@@ -159,6 +161,7 @@ int64_t mbvae_kl_workspace() { return (int64_t)sizeof(float) * 1024; }
 // z = mu + eps*exp(logvar/2); kl[0] = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / numel
 int mbvae_kl_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kl, int64_t numel,
                          void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!mu || !logvar || !eps || !z || !kl || !workspace || numel <= 0) return MBVAE_EINVAL;
   if (ws_bytes < mbvae_kl_workspace()) return MBVAE_EINVAL;
   const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
@@ -171,6 +174,7 @@ int mbvae_kl_reparam_fwd(const float* mu, const float* logvar, const float* eps,
 // dz (may be null) is the gradient wrt z, dkl (device scalar, may be null) wrt the KL value.
 int mbvae_kl_reparam_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* dkl,
                          float* dmu, float* dlogvar, int64_t numel, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!mu || !logvar || !eps || !dmu || !dlogvar || numel <= 0) return MBVAE_EINVAL;
   const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(blocks), dim3(256), 0, stream, mu, logvar, eps, dz, dkl, dmu, dlogvar, numel);

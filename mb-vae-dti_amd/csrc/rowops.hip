@@ -414,6 +414,7 @@ extern "C" {
 int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,
                           float* mean, float* rstd, int64_t rows, int64_t D, float eps, float drop_p, uint64_t seed,
                           hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return MBVAE_EINVAL;
   int st = ln_dispatch(true, D, x, r, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                        rows, eps, drop_p, seed, stream);
@@ -432,6 +433,7 @@ int64_t mbvae_ln_residual_bwd_workspace(int64_t D) { return (int64_t)sizeof(floa
 int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,
                           const float* dy, float* dx, float* dr, float* dgamma, float* dbeta, int64_t rows, int64_t D,
                           float drop_p, uint64_t seed, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !gamma || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0) return MBVAE_EINVAL;
   const int64_t floats = ws_bytes / (int64_t)sizeof(float) - 2 * D;
   if (floats < 2 * D) return MBVAE_EINVAL;
@@ -449,6 +451,7 @@ int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, co
 
 // x [bs,L,D] -> stats [bs,4D] (mean|min|max|std), arg [bs,2,D] int32 (first argmin / argmax along L)
 int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs, int64_t L, int64_t D, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !stats || !arg || bs <= 0 || L <= 0 || D <= 0) return MBVAE_EINVAL;
   if ((D & 3) || bs > 65535 || L > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   const int lpr = (int)(D / 4 < 64 ? D / 4 : 64);
@@ -462,6 +465,7 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
 
 int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg, const float* dstats, float* dx,
                          int64_t bs, int64_t L, int64_t D, int accumulate, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !stats || !arg || !dstats || !dx || bs <= 0 || L <= 0 || D <= 0) return MBVAE_EINVAL;
   if ((D & 3) || bs > 65535) return MBVAE_EUNSUPPORTED;
   int64_t blocks = (L * (D / 4) + 255) / 256;
@@ -474,6 +478,7 @@ int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg,
 // x [bs,n,n,D] (+ optional skip s [bs,n,n,lds] using its first D features) -> out [bs,n,n,D]
 int mbvae_sym_mask(const float* x, const float* s, int64_t lds, const uint8_t* mask, float* out, int64_t bs, int64_t n,
                    int64_t D, int zero_diag, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !mask || !out || bs <= 0 || n <= 0 || D <= 0 || x == out) return MBVAE_EINVAL;
   if (bs * n > 0x7fffffff || n * D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   const bool vec = (D % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0);

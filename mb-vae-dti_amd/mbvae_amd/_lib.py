@@ -48,6 +48,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first (python mb-vae-dti_amd/build.py). "
                            "There is no fallback path.")
+    # torch bundles its own HIP runtime (libamdhip64); it must be in the process BEFORE this library is loaded so
+    # that both share one runtime instance (device pointers and streams are only meaningful within one).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if a declared symbol is not exported
@@ -57,8 +60,22 @@ def load():
     return lib
 
 
-def call(name, *args):
-    st = getattr(load(), name)(*args)
+# When set to a dict, every kernel call is bracketed by HIP events on the current torch stream:
+# PROFILE[(name, tag)] = [(start_event, end_event), ...]   (used by bench.py for per-kernel timings)
+PROFILE = None
+
+
+def call(name, *args, tag=None):
+    fn = getattr(load(), name)
+    if PROFILE is None:
+        st = fn(*args)
+    else:
+        import torch
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        st = fn(*args)
+        end.record()
+        PROFILE.setdefault((name, tag), []).append((start, end))
     if st != 0:
         raise RuntimeError(f"{name} failed: {_STATUS.get(st, st)}")
 

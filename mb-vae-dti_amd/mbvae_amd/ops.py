@@ -58,7 +58,8 @@ class _Linear(torch.autograd.Function):
         ws = workspace(x.device)
         m8 = _mask_u8(mask)
         _lib.call("mbvae_linear_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N, act,
-                  _ptr(m8), mask_mode, n_nodes, float(drop_p), int(seed), 0, ws.data_ptr(), ws.numel(), _stream())
+                  _ptr(m8), mask_mode, n_nodes, float(drop_p), int(seed), 0, ws.data_ptr(), ws.numel(), _stream(),
+                  tag=(M, K, N))
         gated = act == 1
         ctx.save_for_backward(x2, w, y if gated else None, m8)
         ctx.cfg = (mask_mode, n_nodes, float(drop_p), gated, b is not None, x.shape)
@@ -79,13 +80,13 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, _ptr(gate),
-                      gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream())
+                      gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
             dx = dx.reshape(xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             db = torch.empty((N,), dtype=torch.float32, device=dy.device) if has_bias else None
             _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
-                      _ptr(gate), gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream())
+                      _ptr(gate), gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
         return dx, dw, db, None, None, None, None, None, None
 
 
