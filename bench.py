@@ -132,6 +132,15 @@ def main():
             for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"{name:32s} {r['ms'] / args.steps:9.3f} ms/step  {r['calls'] // args.steps:5d} calls/step"
                       f"  {100 * r['ms'] / max(tot, 1e-9):5.1f}%", file=sys.stderr)
+            shapes = {}
+            for (name, tag), evs in profile.items():
+                if tag is not None:
+                    ms = sum(a.elapsed_time(b) for a, b in evs)
+                    shapes[(name, tag)] = (ms, len(evs))
+            for (name, tag), (ms, calls) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:24]:
+                M, K, N = tag
+                print(f"  {name[6:]:18s} M={M:<8d} K={K:<5d} N={N:<5d} {ms / args.steps:8.3f} ms/step {calls // args.steps:4d} calls  "
+                      f"{2.0 * M * K * N * calls / (ms * 1e-3) / 1e12:6.1f} TFLOP/s", file=sys.stderr)
             print(f"{'sum of HIP kernels':32s} {tot / args.steps:9.3f} ms/step;  wall {1000 * elapsed / args.steps:.3f} ms/step",
                   file=sys.stderr)
         # dominant kernel family: edge attention (HBM-bound) vs the MFMA projections (compute-bound)

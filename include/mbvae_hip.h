@@ -119,6 +119,12 @@ int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float
                          int64_t* Ec, float* Xs, float* Es, float* probX, float* probE, int64_t bs, int64_t n,
                          int64_t cx, int64_t ce, mbvae_stream_t stream);
 
+/* ---- batched symmetric eigendecomposition (n <= 64) ----------------------------------------------------
+ * Replaces torch.linalg.eigh on the graph Laplacians, mb_vae_dti/training/diffusion/augmentation.py:68.
+ * A [bs,n,n] symmetric -> W [bs,n] ascending, V [bs,n,n] eigenvectors in columns (signs / degenerate
+ * subspaces are a valid but not LAPACK-identical choice). */
+int mbvae_sym_eig(const float* A, float* W, float* V, int64_t bs, int64_t n, mbvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,13 +160,24 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict
   }
 }
 
-// out[c] = sum_p part[p][c], c < width  (second stage of the per-block partial sums)
-__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int width) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= width) return;
+// out[c] = sum_p part[p][c], c < width  (second stage of the per-block partial sums).
+// block = 32 columns x 8 partial groups; fixed summation order -> deterministic.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nparts, int width) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * width + c];
-  out[c] = s;
+  if (c < width)
+    for (int p = py; p < nparts; p += 8) s += part[(int64_t)p * width + c];
+  red[py][cx] = s;
+  __syncthreads();
+  if (py == 0 && c < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[c] = t;
+  }
 }
 
 template <int LPR, int VPL>
@@ -182,14 +193,14 @@ static int ln_launch(bool fwd, const float* x, const float* r, const float* gamm
     hipLaunchKernelGGL((ln_res_fwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, beta, y,
                        mean, rstd, rows, eps, drop_p, seed);
   } else {
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     if (part_floats < blocks * 2 * D) blocks = part_floats / (2 * D);
     if (blocks < 1) return MBVAE_EINVAL;
     hipLaunchKernelGGL((ln_res_bwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean,
                        rstd, dy, dx, dr, part, rows, drop_p, seed);
     // part is [blocks][2][D]: view as [blocks][2D] and sum -> [2D] = dgamma | dbeta (contiguous in `part` tail)
     float* tail = part + blocks * 2 * D;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, part, tail, (int)blocks, 2 * D);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, part, tail, (int)blocks, 2 * D);
     if (hipMemcpyAsync(dgamma, tail, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
     if (hipMemcpyAsync(dbeta, tail + D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
   }

@@ -5,6 +5,8 @@ ExtraMolecularFeatures :255-276) without their host-synchronising asserts and Py
 """
 import torch
 
+from . import ops
+
 
 def _diag(M):
     return torch.diagonal(M, dim1=-2, dim2=-1)
@@ -49,7 +51,7 @@ class ExtraFeatures:
         L = (L + L.transpose(1, 2)) / 2
         pad = 2 * n * torch.eye(n, device=A.device).unsqueeze(0) * (1 - m).unsqueeze(1) * (1 - m).unsqueeze(2)
         L = L * m.unsqueeze(1) * m.unsqueeze(2) + pad
-        w, V = torch.linalg.eigh(L)
+        w, V = ops.sym_eig(L)
         w = w / m.sum(1, keepdim=True)
         V = V * m.unsqueeze(2) * m.unsqueeze(1)
         ncc = (w < 1e-5).sum(-1)

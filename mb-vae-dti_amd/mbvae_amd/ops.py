@@ -313,6 +313,18 @@ def kl_reparam(mu, logvar, eps):
     return _KLReparam.apply(mu, logvar, eps)
 
 
+# ------------------------------------------------------------------------------------------------ eigensolver
+@torch.no_grad()
+def sym_eig(A):
+    """Batched symmetric eigendecomposition A [bs,n,n] (n <= 64) -> (W ascending [bs,n], V [bs,n,n] columns)."""
+    A = _f32c(A, "A")
+    bs, n, _ = A.shape
+    W = torch.empty((bs, n), dtype=torch.float32, device=A.device)
+    V = torch.empty_like(A)
+    _lib.call("mbvae_sym_eig", A.data_ptr(), W.data_ptr(), V.data_ptr(), bs, n, _stream())
+    return W, V
+
+
 # ------------------------------------------------------------------------------------------------ diffusion samplers
 @torch.no_grad()
 def apply_noise(X0, E0, node_mask, abar_t, mx, me, expX, expE):

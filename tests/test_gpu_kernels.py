@@ -340,3 +340,56 @@ def test_denoiser_realwidth_golden():
         out = net(g["X"].cuda(), g["E"].cuda(), g["y"].cuda(), g["mask"].bool().cuda())
     assert_close(out.X, g["out_X"], what="X"); assert_close(out.E, g["out_E"], what="E")
     assert_close(out.y, g["out_y"], rtol=2e-5, what="y")
+
+
+# ------------------------------------------------------------------------------------------------ eigensolver + features
+@pytest.mark.parametrize("bs,n", [(8, 64), (5, 9), (3, 33), (4, 1), (2, 2)])
+def test_sym_eig(ops, bs, n):
+    g = torch.Generator().manual_seed(n)
+    A = (torch.rand(bs, n, n, generator=g) < 0.15).float()
+    A = torch.triu(A, 1); A = A + A.transpose(1, 2)
+    if bs > 2:
+        A[1, : n // 2, n // 2:] = 0; A[1, n // 2:, : n // 2] = 0           # two components
+        A[2] = 0                                                            # no edges at all
+    L = torch.diag_embed(A.sum(-1)) - A
+    W, V = ops.sym_eig(L.cuda())
+    W, V = W.cpu().double(), V.cpu().double()
+    ref = torch.linalg.eigvalsh(L.double())
+    assert_close(W, ref, rtol=1e-5, what="eigenvalues")
+    assert bool((W[:, 1:] >= W[:, :-1]).all()), "ascending"
+    Ld = L.double()
+    resid = Ld @ V - V * W.unsqueeze(1)
+    assert float(resid.abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    eye = torch.eye(n, dtype=torch.float64)
+    # fp32 Jacobi: ~600 accumulated plane rotations per column leave V orthonormal to a few 1e-5
+    assert float((V.transpose(1, 2) @ V - eye).abs().max()) < 5e-5
+
+
+def test_extra_features_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.features import ExtraFeatures, ExtraMolecularFeatures
+    g = load_golden("features")
+    mask = g["mask"].bool().cuda()
+    X_t, E_t = g["X_t"].cuda(), g["E_t"].cuda()
+    torch.manual_seed(0)
+    Xg, yg = ExtraFeatures(int(g["max_n_nodes"]))(E_t, mask)
+    Xm, ym = ExtraMolecularFeatures(g["valencies"].tolist(), float(g["max_weight"]), g["atom_weights"].tolist())(X_t, E_t)
+    Xe = torch.cat((Xg, Xm), 2).cpu()
+    ye = torch.cat((yg, ym, g["t"].cuda()), 1).cpu()
+    ref = g["X_extra"]
+    assert_close(Xe[..., :3], ref[..., :3], what="cycle features")
+    assert_close(Xe[..., 6:], ref[..., 6:], what="charge / valency")
+    assert_close(ye, g["y_extra"], rtol=1e-5, what="y_extra (n, cycles, components, eigenvalues, weight, t)")
+    # eigenvector features are gauge dependent: check them against the Laplacian instead of LAPACK's choice
+    L = g["laplacian"].double()
+    m = g["mask"].bool()
+    for b in range(L.shape[0]):
+        nv = int(m[b].sum())
+        for col in (4, 5):
+            v = Xe[b, :, col].double()
+            if float(v.abs().max()) == 0:
+                continue
+            lam = float(v @ (L[b] @ v) / (v @ v))
+            assert float(((L[b] @ v) - lam * v).abs().max()) < 1e-4, "not an eigenvector"
+            assert abs(float(v @ v) - 1.0) < 1e-4 and float(v[nv:].abs().max() if nv < len(v) else 0) == 0
