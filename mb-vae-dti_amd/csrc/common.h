@@ -36,14 +36,15 @@ __device__ __forceinline__ float mbvae_drop_scale(float p, uint64_t seed, uint64
   return mbvae_u01(seed, idx) < p ? 0.f : 1.f / (1.f - p);
 }
 
-// 1.0f if row r survives the mask, else 0.0f.
+// 1.0f if row r survives the mask, else 0.0f.  Row counts are < 2^31 (checked by the callers): 32-bit divides.
 __device__ __forceinline__ float mbvae_row_keep(const uint8_t* mask, int mode, int64_t r, int n) {
   if (mode == MBVAE_MASK_NONE) return 1.f;
   if (mode == MBVAE_MASK_NODE) return mask[r] ? 1.f : 0.f;
-  int64_t bi = r / n;            // b*n + i
-  int64_t j = r - bi * n;
-  int64_t b = bi / n;
-  return (mask[bi] && mask[b * n + j]) ? 1.f : 0.f;
+  const unsigned un = (unsigned)n, ur = (unsigned)r;
+  const unsigned bi = ur / un;          // b*n + i
+  const unsigned j = ur - bi * un;
+  const unsigned b = bi / un;
+  return (mask[bi] && mask[b * un + j]) ? 1.f : 0.f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

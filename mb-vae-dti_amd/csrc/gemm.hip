@@ -44,7 +44,9 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int r
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+// FAST: every tile is full and 16-byte aligned (M % BM == 0, N % BN == 0, k range % 32 == 0, ld % 4 == 0), so the
+// staging loads are unconditional float4 loads with no bounds logic; GATE: the A prologue has a gate operand.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool FAST, bool GATE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // staged floats per thread
   static_assert(WM * WN == 4, "4 waves");
   __shared__ __align__(16) float smem[BK * LDAS + BK * LDBS];
+  __shared__ float keepM[BM];        // row-mask flags of the tile's M rows (epilogue mask, or A prologue when A_KC)
+  __shared__ float keepK[2][BK];     // row-mask flags of the current k rows (A prologue when !A_KC), double-buffered
   float* As = smem;
   float* Bs = smem + BK * LDAS;
 
@@ -66,8 +70,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const bool vecA = (((uintptr_t)g.A & 15) == 0) && ((g.lda & 3) == 0) &&
                     (g.a_gate == nullptr || ((uintptr_t)g.a_gate & 15) == 0);
   const bool vecB = (((uintptr_t)g.B & 15) == 0) && ((g.ldb & 3) == 0);
+  {
+    const int mode_m = A_KC ? (g.a_mask_mode | g.c_mask_mode) : g.c_mask_mode;
+    if (tid < BM) keepM[tid] = (m0 + tid < g.M) ? mbvae_row_keep(g.mask, mode_m, m0 + tid, g.n_nodes) : 0.f;
+  }
+  __syncthreads();
 
-  float ra[RA], rb[RB];
+  // Staging registers: raw operand words (and gate words) of the NEXT k-tile.  fetch() only issues the global
+  // loads; the prologue arithmetic (gate, row mask) runs in commit(), one k-tile later, so the loads stay in
+  // flight underneath the MFMA loop instead of being waited for right after issue.
+  float ra[RA], rb[RB], rg[RA];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -76,134 +88,97 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
   float colsum = 0.f;
+  constexpr bool has_gate = GATE;
+
+  // element (row, col) of a [rows x cols] row-major operand tile slot: 4 consecutive floats starting at `off`,
+  // valid while col + q < col_end; rows beyond row_end give zeros.
+  auto load4 = [&](const float* base, bool vec, int64_t off, bool row_ok, int col, int col_end, float* dst) {
+    if (FAST) {
+      const float4 t = *reinterpret_cast<const float4*>(base + off);
+      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+      return;
+    }
+    dst[0] = dst[1] = dst[2] = dst[3] = 0.f;
+    if (!row_ok) return;
+    if (vec && col + 3 < col_end) {
+      const float4 t = *reinterpret_cast<const float4*>(base + off);
+      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (col + q < col_end) dst[q] = base[off + q];
+    }
+  };
 
   auto fetch = [&](int kt) {
-    // ---- A
+    if (!A_KC && g.a_mask_mode != MBVAE_MASK_NONE && tid < BK)
+      keepK[(kt >> 5) & 1][tid] = (kt + tid < kend) ? mbvae_row_keep(g.mask, g.a_mask_mode, kt + tid, g.n_nodes) : 0.f;
     if (A_KC) {
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
-        const int row = m0 + (tid >> 3) + 32 * p;
-        const int kc = kt + (tid & 7) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < g.M) {
-          const int64_t off = (int64_t)row * g.lda + kc;
-          const float keep = mbvae_row_keep(g.mask, g.a_mask_mode, row, g.n_nodes) * g.a_gate_scale;
-          if (vecA && kc + 3 < kend) {
-            float4 t = *reinterpret_cast<const float4*>(g.A + off);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            if (g.a_gate) {
-              float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
-              v[0] = q.x > 0.f ? v[0] : 0.f; v[1] = q.y > 0.f ? v[1] : 0.f;
-              v[2] = q.z > 0.f ? v[2] : 0.f; v[3] = q.w > 0.f ? v[3] : 0.f;
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (kc + q < kend) {
-                float t = g.A[off + q];
-                if (g.a_gate && !(g.a_gate[off + q] > 0.f)) t = 0.f;
-                v[q] = t;
-              }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] *= keep;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ra[p * 4 + q] = v[q];
+        const int row = m0 + (tid >> 3) + 32 * p, kc = kt + (tid & 7) * 4;
+        const int64_t off = (int64_t)row * g.lda + kc;
+        load4(g.A, vecA, off, row < g.M, kc, kend, &ra[p * 4]);
+        if (has_gate) load4(g.a_gate, vecA, off, row < g.M, kc, kend, &rg[p * 4]);
       }
     } else {
       constexpr int ROWS_PER_PASS = 1024 / BM;
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
-        const int mq = tid % (BM / 4);
-        const int krow = kt + tid / (BM / 4) + ROWS_PER_PASS * p;
-        const int mc = m0 + mq * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (krow < kend) {
-          const int64_t off = (int64_t)krow * g.lda + mc;
-          const float keep = mbvae_row_keep(g.mask, g.a_mask_mode, krow, g.n_nodes) * g.a_gate_scale;
-          if (vecA && mc + 3 < g.M) {
-            float4 t = *reinterpret_cast<const float4*>(g.A + off);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            if (g.a_gate) {
-              float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
-              v[0] = q.x > 0.f ? v[0] : 0.f; v[1] = q.y > 0.f ? v[1] : 0.f;
-              v[2] = q.z > 0.f ? v[2] : 0.f; v[3] = q.w > 0.f ? v[3] : 0.f;
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (mc + q < g.M) {
-                float t = g.A[off + q];
-                if (g.a_gate && !(g.a_gate[off + q] > 0.f)) t = 0.f;
-                v[q] = t;
-              }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] *= keep;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ra[p * 4 + q] = v[q];
+        const int krow = kt + tid / (BM / 4) + ROWS_PER_PASS * p, mc = m0 + (tid % (BM / 4)) * 4;
+        const int64_t off = (int64_t)krow * g.lda + mc;
+        load4(g.A, vecA, off, krow < kend, mc, g.M, &ra[p * 4]);
+        if (has_gate) load4(g.a_gate, vecA, off, krow < kend, mc, g.M, &rg[p * 4]);
       }
     }
-    // ---- B
     if (B_KC) {
 #pragma unroll
       for (int p = 0; p < BN / 32; ++p) {
-        const int row = n0 + (tid >> 3) + 32 * p;
-        const int kc = kt + (tid & 7) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < g.N) {
-          const int64_t off = (int64_t)row * g.ldb + kc;
-          if (vecB && kc + 3 < kend) {
-            float4 t = *reinterpret_cast<const float4*>(g.B + off);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (kc + q < kend) v[q] = g.B[off + q];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rb[p * 4 + q] = v[q];
+        const int row = n0 + (tid >> 3) + 32 * p, kc = kt + (tid & 7) * 4;
+        load4(g.B, vecB, (int64_t)row * g.ldb + kc, row < g.N, kc, kend, &rb[p * 4]);
       }
     } else {
       constexpr int ROWS_PER_PASS = 1024 / BN;
 #pragma unroll
       for (int p = 0; p < BN / 32; ++p) {
-        const int nq = tid % (BN / 4);
-        const int krow = kt + tid / (BN / 4) + ROWS_PER_PASS * p;
-        const int nc = n0 + nq * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (krow < kend) {
-          const int64_t off = (int64_t)krow * g.ldb + nc;
-          if (vecB && nc + 3 < g.N) {
-            float4 t = *reinterpret_cast<const float4*>(g.B + off);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (nc + q < g.N) v[q] = g.B[off + q];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rb[p * 4 + q] = v[q];
+        const int krow = kt + tid / (BN / 4) + ROWS_PER_PASS * p, nc = n0 + (tid % (BN / 4)) * 4;
+        load4(g.B, vecB, (int64_t)krow * g.ldb + nc, krow < kend, nc, g.N, &rb[p * 4]);
       }
     }
   };
 
-  auto commit = [&]() {
+  // kt = first reduction index of the tile held in the staging registers
+  auto commit = [&](int kt) {
+    const bool prologue = has_gate || g.a_mask_mode != MBVAE_MASK_NONE || g.a_gate_scale != 1.f;
     if (A_KC) {
 #pragma unroll
-      for (int p = 0; p < BM / 32; ++p)
+      for (int p = 0; p < BM / 32; ++p) {
+        float keep = 1.f;
+        if (prologue) keep = (g.a_mask_mode != MBVAE_MASK_NONE ? keepM[(tid >> 3) + 32 * p] : 1.f) * g.a_gate_scale;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) As[((tid & 7) * 4 + q) * LDAS + (tid >> 3) + 32 * p] = ra[p * 4 + q];
+        for (int q = 0; q < 4; ++q) {
+          float v = ra[p * 4 + q];
+          if (has_gate && !(rg[p * 4 + q] > 0.f)) v = 0.f;
+          if (prologue) v *= keep;
+          As[((tid & 7) * 4 + q) * LDAS + (tid >> 3) + 32 * p] = v;
+        }
+      }
     } else {
       constexpr int ROWS_PER_PASS = 1024 / BM;
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
-        float4 t = make_float4(ra[p * 4], ra[p * 4 + 1], ra[p * 4 + 2], ra[p * 4 + 3]);
-        *reinterpret_cast<float4*>(&As[(tid / (BM / 4) + ROWS_PER_PASS * p) * LDAS + (tid % (BM / 4)) * 4]) = t;
+        float keep = 1.f;
+        if (prologue)
+          keep = (g.a_mask_mode != MBVAE_MASK_NONE ? keepK[(kt >> 5) & 1][tid / (BM / 4) + ROWS_PER_PASS * p] : 1.f) * g.a_gate_scale;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = ra[p * 4 + q];
+          if (has_gate && !(rg[p * 4 + q] > 0.f)) v[q] = 0.f;
+          if (prologue) v[q] *= keep;
+        }
+        *reinterpret_cast<float4*>(&As[(tid / (BM / 4) + ROWS_PER_PASS * p) * LDAS + (tid % (BM / 4)) * 4]) =
+            make_float4(v[0], v[1], v[2], v[3]);
       }
     }
     if (B_KC) {
@@ -214,10 +189,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     } else {
       constexpr int ROWS_PER_PASS = 1024 / BN;
 #pragma unroll
-      for (int p = 0; p < BN / 32; ++p) {
-        float4 t = make_float4(rb[p * 4], rb[p * 4 + 1], rb[p * 4 + 2], rb[p * 4 + 3]);
-        *reinterpret_cast<float4*>(&Bs[(tid / (BN / 4) + ROWS_PER_PASS * p) * LDBS + (tid % (BN / 4)) * 4]) = t;
-      }
+      for (int p = 0; p < BN / 32; ++p)
+        *reinterpret_cast<float4*>(&Bs[(tid / (BN / 4) + ROWS_PER_PASS * p) * LDBS + (tid % (BN / 4)) * 4]) =
+            make_float4(rb[p * 4], rb[p * 4 + 1], rb[p * 4 + 2], rb[p * 4 + 3]);
     }
   };
 
@@ -225,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   if (kbeg < kend) fetch(kbeg);
   for (int kt = kbeg; kt < kend; kt += BK) {
     __syncthreads();                 // previous tile fully consumed
-    commit();
+    commit(kt);
     __syncthreads();
     if (kt + BK < kend) fetch(kt + BK);
     if (want_colsum && tid < BM) {
@@ -247,25 +221,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
   }
 
-  // ---- write back.  C/D layout of the 32x32 tile: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+  // ---- write back.  C/D layout of the 32x32 tile: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5).
+  // Bias values and row-mask flags are fetched up front: loads issued between the stores would each be waited
+  // for (the stores may alias them as far as the compiler knows) and serialise the epilogue on L2 latency.
   const bool split = g.partial != nullptr;
+  float bj[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    bj[j] = (!split && g.bias && (FAST || col < g.N)) ? g.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float keep[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-      if (row >= g.M) continue;
-      const float keep = split ? 1.f : mbvae_row_keep(g.mask, g.c_mask_mode, row, g.n_nodes);
+      keep[v] = (split || g.c_mask_mode == MBVAE_MASK_NONE) ? 1.f : keepM[row - m0];
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (!FAST && row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + r;
-        if (col >= g.N) continue;
-        if (split)
+        if (!FAST && col >= g.N) continue;
+        if (split) {
           g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][v];
-        else
-          g.C[(int64_t)row * g.ldc + col] = gemm_epilogue(g, acc[i][j][v], row, col, keep);
+        } else {
+          float o = acc[i][j][v] + bj[j];
+          if (g.act == 1) o = fmaxf(o, 0.f);
+          if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
+          o *= keep[v];
+          if (g.accumulate) o += g.C[(int64_t)row * g.ldc + col];
+          g.C[(int64_t)row * g.ldc + col] = o;
+        }
       }
     }
+  }
   if (want_colsum && tid < BM && m0 + tid < g.M) {
     if (split) g.partial_colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = colsum;
     else g.colsum[m0 + tid] = colsum;
@@ -318,9 +312,20 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
     g.partial = nullptr; g.partial_colsum = nullptr;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)splits), block(256);
-  if (BM == 64) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, A_KC, B_KC>), grid, block, 0, stream, g);
-  else if (BN == 64) hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 4, 1, A_KC, B_KC>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, A_KC, B_KC>), grid, block, 0, stream, g);
+  const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
+  const bool fast = aligned && g.M % BM == 0 && g.N % BN == 0 && g.K % 32 == 0;
+  const bool gate = g.a_gate != nullptr;
+#define GEMM_LAUNCH(bm, bn, wm, wn)                                                                                     \
+  do {                                                                                                                   \
+    if (fast && gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, true>), grid, block, 0, stream, g);        \
+    else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, false>), grid, block, 0, stream, g);          \
+    else if (gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, true>), grid, block, 0, stream, g);          \
+    else hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, false>), grid, block, 0, stream, g);                   \
+  } while (0)
+  if (BM == 64) GEMM_LAUNCH(64, 64, 2, 2);
+  else if (BN == 64) GEMM_LAUNCH(128, 64, 4, 1);
+  else GEMM_LAUNCH(128, 128, 2, 2);
+#undef GEMM_LAUNCH
   if (splits > 1) {
     const int64_t total = (int64_t)g.M * g.N + g.M;
     int blocks = (int)std::min<int64_t>(2048, (total + 255) / 256);

@@ -1,0 +1,33 @@
+"""Micro-benchmark of the linear kernels on the E-path shapes (GPU box only)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mb-vae-dti_amd")); sys.path.insert(0, ROOT)
+import torch
+from mbvae_amd import ops
+
+def timeit(fn, iters=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+bs, n = 256, 64
+M = bs * n * n
+mask = torch.ones(bs, n, dtype=torch.bool, device="cuda")
+for K, N in ((64, 256), (256, 64), (64, 128), (128, 64)):
+    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
+    dy = torch.randn(M, N, device="cuda")
+    for mode, mm in (("none", None), ("edge", mask)):
+        with torch.no_grad():
+            t = timeit(lambda: ops.linear(x, w, b, mask=mm, mask_mode=ops.MASK_EDGE, n_nodes=n))
+        print(f"fwd  K={K:4d} N={N:4d} mask={mode:5s} {t*1000:8.1f} us  {2*M*K*N/t/1e9:7.1f} TFLOP/s  {(M*K+M*N)*4/t/1e6:7.1f} GB/s", flush=True)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y = ops.linear(xr, wr, b, mask=mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
+    def bw():
+        xr.grad = None; wr.grad = None
+        y.backward(dy, retain_graph=True)
+    t = timeit(bw)
+    print(f"bwd(in+w) K={K:4d} N={N:4d} mask=edge  {t*1000:8.1f} us  {4*M*K*N/t/1e9:7.1f} TFLOP/s", flush=True)
