@@ -38,7 +38,7 @@ class ExtraFeatures:
     def __init__(self, max_n_nodes=64):
         self.max_n_nodes = max_n_nodes
 
-    def __call__(self, E_t, node_mask):
+    def __call__(self, E_t, node_mask, lcc_noise=None):
         bs, n = node_mask.shape
         m = node_mask.float()
         A_raw = E_t[..., 1:].sum(-1).float()
@@ -59,7 +59,8 @@ class ExtraFeatures:
         k_val, k_vec = 5, 2
         w_ext = torch.cat((w, 2 * torch.ones(bs, k_val, device=w.device)), 1)
         vals = torch.gather(w_ext, 1, torch.arange(k_val, device=w.device).unsqueeze(0) + ncc.unsqueeze(1))
-        first = torch.round(V[:, :, 0], decimals=3) * m + torch.randn(bs, n, device=m.device) * (1 - m)
+        noise = torch.randn(bs, n, device=m.device) if lcc_noise is None else lcc_noise
+        first = torch.round(V[:, :, 0], decimals=3) * m + noise * (1 - m)
         mode = torch.mode(first, dim=1).values
         not_lcc = ((first != mode.unsqueeze(1)) & node_mask).unsqueeze(-1).float()
         V_ext = torch.cat((V, torch.zeros(bs, n, k_vec, device=V.device)), 2)
@@ -75,11 +76,15 @@ class ExtraMolecularFeatures:
     def __init__(self, valencies, max_weight, atom_weights):
         self.valencies, self.max_weight, self.atom_weights = list(valencies), max_weight, list(atom_weights)
 
-    def __call__(self, X_t, E_t):
+    def __call__(self, X_t, E_t, truncate_weight=False):
+        """truncate_weight: the reference's training path hands int64 one-hot tensors to this feature, which makes
+        its `.type_as(X_t)` truncate the summed atomic weight to an integer before the division by max_weight;
+        the sampling path passes floats and keeps the fraction.  Callers pick the behaviour of the path they mirror."""
         dev = X_t.device
         orders = torch.tensor([0, 1, 2, 3, 1.5], device=dev).reshape(1, 1, 1, -1)
         cur = (E_t * orders).argmax(-1).sum(-1)                               # integer "valency" as in the reference
         normal = (X_t * torch.tensor(self.valencies, device=dev).reshape(1, 1, -1)).argmax(-1)
         charge = (normal - cur).type_as(X_t)
-        weight = torch.tensor(self.atom_weights, device=dev)[X_t.argmax(-1)].sum(-1, keepdim=True).type_as(X_t) / self.max_weight
+        weight = torch.tensor(self.atom_weights, device=dev)[X_t.argmax(-1)].sum(-1, keepdim=True)
+        weight = (torch.trunc(weight) if truncate_weight else weight).type_as(X_t) / self.max_weight
         return torch.stack((charge, cur.type_as(X_t)), -1), weight

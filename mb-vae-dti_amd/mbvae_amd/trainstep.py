@@ -67,7 +67,7 @@ class DenoiserTrainStep:
         eX, eE = exp_draws(bs * n, cx, dev), exp_draws(bs * n * n, ce, dev)
         _, _, X_t, E_t = ops.apply_noise(X0, E0, mask, abar_t, self.mx, self.me, eX, eE)
         Xg, yg = self.graph_feats(E_t, mask)
-        Xm, ym = self.mol_feats(X_t, E_t)
+        Xm, ym = self.mol_feats(X_t, E_t, truncate_weight=True)
         X_in = torch.cat((X_t, Xg, Xm), 2)
         y_in = torch.cat((cond, yg, ym, t), 1)
         pred = self.model(X_in, E_t, y_in, mask)

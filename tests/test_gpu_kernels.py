@@ -393,3 +393,102 @@ def test_extra_features_golden():
             lam = float(v @ (L[b] @ v) / (v @ v))
             assert float(((L[b] @ v) - lam * v).abs().max()) < 1e-4, "not an eigenvector"
             assert abs(float(v @ v) - 1.0) < 1e-4 and float(v[nv:].abs().max() if nv < len(v) else 0) == 0
+
+
+# ------------------------------------------------------------------------------------------------ full model (boundary)
+def _tiny_full_model(phase, g, seed_sd):
+    from mbvae_amd.full import FullDTIModel
+    cx, emb, hid = 8, 32, 16
+    infos = {"general": {"atom_types": ["C", "O", "P", "N", "S", "Cl", "F", "H"], "max_n_nodes": 64,
+                         "atom_valencies": [4, 2, 3, 3, 2, 1, 1, 1],
+                         "atom_weights": [12.011, 15.999, 30.974, 14.007, 32.06, 35.45, 18.998, 1.008], "max_weight": 1000},
+             "dataset": {"node_count_distribution": {"3": 1, "5": 2, "7": 3, "9": 2}, "node_marginals": g["mx"].tolist(),
+                         "edge_marginals": g["me"].tolist()}}
+    gt = dict(n_layers=2, input_dims={"X": cx + 8, "E": 5, "y": emb + 13}, output_dims={"X": cx, "E": 5, "y": emb},
+              hidden_mlp_dims={"X": 24, "E": 16, "y": 40},
+              hidden_dims={"dx": 32, "de": 16, "dy": 32, "n_head": 4, "dim_ffX": 24, "dim_ffE": 16, "dim_ffy": 40})
+    model = FullDTIModel(
+        phase=phase, finetune_score=None, learning_rate=5e-4, weight_decay=1e-4, scheduler="const", weights=[1.0, 0.001, 0.5, 3.0],
+        dti_weights=[1.0, 0.903964, 0.282992, 0.755172] if phase == "train" else None, diff_weights=[1, 5], contrastive_temp=0.1,
+        drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 24},
+        target_features={"FP-ESP": 48, "EMB-ESM": 40, "EMB-NT": 20} if phase == "train" else {},
+        embedding_dim=emb, hidden_dim=hid, factor=4, n_layers=2, activation="relu", dropout=0.1, bias=True,
+        encoder_type="transformer", aggregator_type="attentive", diffusion_steps=500, sample_every_val=5,
+        val_samples_per_embedding=2, test_samples_per_embedding=2, graph_transformer_kwargs=gt, dataset_infos=infos)
+    missing, unexpected = model.load_state_dict(seed_sd, strict=False)
+    assert not missing, f"state_dict keys missing from the reference checkpoint: {missing}"
+    return model.cuda()
+
+
+def test_full_model_common_step_golden():
+    """FullDTIModel._common_step('train') on the reference's own random draws: every intermediate and loss component."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.containers import GraphData
+    g = load_golden("common_step")
+    model = _tiny_full_model("train", g, g["sd"])
+    model.eval()                       # dropout off (the fixture was captured that way) ...
+    model.training = True              # ... but t ~ U{0..T} as in training
+    model.replay = {k: g[k] for k in ("t_int", "expX", "expE", "lcc_noise", "eps")}
+    mask = g["mask"].bool().cuda()
+    gd = GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)
+    y = {k: (v.bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
+    batch = {"id": torch.arange(4), "y": y,
+             "drug": {"features": {k: v.cuda() for k, v in g["feat_d"].items()}, "representations": {"smiles": ["C"] * 4}, "G": gd},
+             "target": {"features": {k: v.cuda() for k, v in g["feat_t"].items()}}}
+    bd, emb, pred, loss = model._common_step(batch, "train")
+    total = loss.compute_loss(model.weights)
+    assert torch.equal(bd.graph_data.X_t.cpu(), g["X_t"]) and torch.equal(bd.graph_data.E_t.cpu(), g["E_t"])
+    assert_close(bd.graph_data.y_extra, g["y_extra"], what="y_extra")
+    assert_close(bd.graph_data.X_extra[..., :3], g["X_extra"][..., :3], what="X_extra cycles")
+    assert_close(bd.graph_data.X_extra[..., 6:], g["X_extra"][..., 6:], what="X_extra charge/valency")
+    assert_close(emb.drug_mu, g["drug_mu"], what="mu"); assert_close(emb.drug_logvar, g["drug_logvar"], what="logvar")
+    assert_close(emb.drug_embedding, g["drug_embedding"], what="z")
+    assert_close(emb.target_embedding, g["target_embedding"], what="target embedding")
+    assert_close(emb.fused_embedding, g["fused"], what="fused")
+    assert_close(loss.accuracy, g["loss_accuracy"], what="accuracy"); assert_close(loss.complexity, g["loss_complexity"], what="kl")
+    assert_close(loss.contrastive, g["loss_contrastive"], what="contrastive")
+    # eigenvector input features are gauge dependent (sign): inject the reference's and compare the decoder exactly
+    bd.graph_data.X_extra = g["X_extra"].cuda()
+    out = model.denoise_drug_graph(emb, bd)
+    assert_close(out.X, g["pred_X"], rtol=2e-5, what="pred X"); assert_close(out.E, g["pred_E"], rtol=2e-5, what="pred E")
+    rec = model.reconstruction_head(out.X, out.E, bd.graph_data.X, bd.graph_data.E)
+    assert_close(rec, g["loss_reconstruction"], what="reconstruction")
+    loss.reconstruction = rec
+    total = loss.compute_loss(model.weights)
+    assert_close(total, g["loss_total"], what="total")
+    total.backward()
+    for k, v in g["grad"].items():
+        assert_close(dict(model.named_parameters())[k].grad, v, rtol=5e-5, what="grad " + k)
+    for k, v in g["gradnorm"].items():
+        got = dict(model.named_parameters())[k].grad
+        assert got is not None, k
+        assert abs(float(got.norm()) - float(v)) <= 1e-4 * max(1.0, float(v)), f"grad norm {k}: {float(got.norm())} vs {float(v)}"
+
+
+def test_full_model_sampling_and_val_step_run():
+    """sample_batch (5 reverse steps) yields symmetric, masked class-id graphs; validation_step returns a finite NLL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.containers import GraphData
+    g = load_golden("common_step")
+    sd = {k: v for k, v in g["sd"].items() if k.startswith("drug_") or k.startswith("noise_schedule")}
+    model = _tiny_full_model("pretrain_drug", g, sd)
+    model.T = 5
+    model.noise_schedule = type(model.noise_schedule)(5).cuda()
+    model.eval()
+    torch.manual_seed(0)
+    emb = torch.randn(3, 32, device="cuda")
+    groups = model.sample_batch(emb, num_nodes=torch.tensor([9, 4, 6]), num_samples_per_embedding=2, return_graphs=True)
+    assert len(groups) == 3 and all(len(x) == 2 for x in groups)
+    for grp, n in zip(groups, (9, 4, 6)):
+        for atoms, bonds in grp:
+            assert atoms.shape == (n,) and bonds.shape == (n, n)
+            assert int(atoms.min()) >= 0 and int(atoms.max()) < 8 and torch.equal(bonds, bonds.T)
+            assert int(bonds.diagonal().abs().sum()) == 0 and int(bonds.max()) < 5
+    mask = g["mask"].bool().cuda()
+    batch = {"features": {k: v.cuda() for k, v in g["feat_d"].items()}, "representations": {"smiles": ["C"] * 4},
+             "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}
+    with torch.no_grad():
+        nll = model.validation_step(batch, 0)
+    assert torch.isfinite(nll)
