@@ -55,16 +55,19 @@ class MarginalUniformTransition:
         self.x_marginals, self.e_marginals = x_marginals, e_marginals
 
     @staticmethod
-    def _build(coef_eye, marg, device):
+    def _mix(w_eye, w_marg, marg, device):
+        """w_eye * I + w_marg * 1 m^T per graph -> [bs, c, c] (weights given separately: 1 - (1 - b) != b in fp32)."""
         c = marg.numel()
-        a = coef_eye.to(device).reshape(-1, 1, 1)
-        return a * torch.eye(c, device=device).unsqueeze(0) + (1 - a) * marg.to(device).reshape(1, 1, c).expand(1, c, c)
+        return (w_eye.to(device).reshape(-1, 1, 1) * torch.eye(c, device=device).unsqueeze(0)
+                + w_marg.to(device).reshape(-1, 1, 1) * marg.to(device).reshape(1, 1, c).expand(1, c, c))
 
     def get_Qt(self, beta_t, device):
-        return PlaceHolder(X=self._build(1 - beta_t, self.x_marginals, device), E=self._build(1 - beta_t, self.e_marginals, device))
+        return PlaceHolder(X=self._mix(1 - beta_t, beta_t, self.x_marginals, device),
+                           E=self._mix(1 - beta_t, beta_t, self.e_marginals, device))
 
     def get_Qt_bar(self, alpha_bar_t, device):
-        return PlaceHolder(X=self._build(alpha_bar_t, self.x_marginals, device), E=self._build(alpha_bar_t, self.e_marginals, device))
+        return PlaceHolder(X=self._mix(alpha_bar_t, 1 - alpha_bar_t, self.x_marginals, device),
+                           E=self._mix(alpha_bar_t, 1 - alpha_bar_t, self.e_marginals, device))
 
 
 class DistributionNodes:
