@@ -47,6 +47,18 @@ __device__ __forceinline__ float mbvae_row_keep(const uint8_t* mask, int mode, i
   return (mask[bi] && mask[b * un + j]) ? 1.f : 0.f;
 }
 
+// Raw mask bytes deciding whether row r survives (both must be non-zero).  Lets a kernel issue the loads early and
+// combine them later, so that no arithmetic waits on them at the issue point.
+__device__ __forceinline__ void mbvae_row_mask_bytes(const uint8_t* mask, int mode, int64_t r, int n, uint8_t& a, uint8_t& b) {
+  a = 1; b = 1;
+  if (mode == MBVAE_MASK_NODE) { a = mask[r]; return; }
+  if (mode == MBVAE_MASK_EDGE) {
+    const unsigned un = (unsigned)n, ur = (unsigned)r;
+    const unsigned bi = ur / un, j = ur - bi * un, bb = bi / un;
+    a = mask[bi]; b = mask[bb * un + j];
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -17,6 +17,7 @@
 // second kernel that also applies the epilogue, which keeps results bitwise reproducible.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -63,8 +64,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear block id so that
+  // the N-tiles of one M-tile (which re-read the same A rows) run on ONE XCD, back to back: speed only.
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, per = nt / 8, rem = nt % 8, xcd = tile % 8, k = tile / 8;
+    tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + k;     // bijective for any grid size
+  }
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const bool vecA = (((uintptr_t)g.A & 15) == 0) && ((g.lda & 3) == 0) &&
@@ -284,14 +292,197 @@ __global__ void gemm_reduce_kernel(GemmArgs g, int splits) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent "tall-skinny" product for the edge path: C[M,N] = epi( pro(A)[M,K] @ Bm[K,N] ) with M ~ 10^6 rows and a
+// weight matrix small enough (K*N*4 <= 64 KB) to stay in LDS for the whole kernel.  One 512-thread workgroup per CU
+// walks over 128/256-row tiles of A: the weights are staged once, A arrives in 32-wide k-chunks through a
+// double-buffered LDS ring whose next chunk (possibly the next tile's first) is already in flight in registers while
+// the current one is multiplied, so HBM latency and the epilogue stores hide under the MFMA stream and there is one
+// barrier per chunk.  A is k-contiguous (activations or their gradients); Bm is either W[N,K] (forward, B_KC) or
+// W[K,N] (input gradient).
+template <int N, int BM, int WM, int WN, bool B_KC, bool GATE>
+__global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / (32 * WM), TN = N / (32 * WN);
+  constexpr int LDA = BM + 1, LDB = N + 1;
+  constexpr int PASSES = BM / 64;                  // 8 threads x float4 cover one 32-wide row chunk, 64 rows per pass
+  static_assert(WM * WN == 8, "8 waves");
+  extern __shared__ __align__(16) float ts_smem[];
+  float* Bs = ts_smem;                             // [K][LDB]
+  float* As = Bs + g.K * LDB;                      // [2][BK][LDA]
+  float* keepS = As + 2 * BK * LDA;                // [2][BM]  row-mask flags of the tile (epilogue)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int K = g.K;
+  const int cpt = K / BK;                          // chunks per tile
+  const int ntiles = g.M / BM;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * cpt;
+  const int mask_mode = g.a_mask_mode | g.c_mask_mode;
+  const bool prologue = GATE || g.a_mask_mode != MBVAE_MASK_NONE || g.a_gate_scale != 1.f;
+
+  // ---- weights -> LDS (k-major), once
+  if (B_KC) {
+    for (int e = tid; e < N * K; e += 512) { const int n = e / K, k = e - n * K; Bs[k * LDB + n] = g.B[(int64_t)n * g.ldb + k]; }
+  } else {
+    for (int e = tid; e < N * K; e += 512) { const int k = e / N, n = e - k * N; Bs[k * LDB + n] = g.B[(int64_t)k * g.ldb + n]; }
+  }
+
+  float ra[PASSES * 4], rg[PASSES * 4];
+  uint8_t ma[PASSES], mb[PASSES], ta = 1, tb = 1;     // raw mask bytes: rows of the staged chunk / this thread's tile row
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  auto fetch = [&](int c) {
+    const int lt = c / cpt, kc = (c - lt * cpt) * BK;
+    const int m0 = ((int)blockIdx.x + lt * (int)gridDim.x) * BM;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = m0 + (tid >> 3) + 64 * p;
+      const int64_t off = (int64_t)row * g.lda + kc + (tid & 7) * 4;
+      const float4 t = *reinterpret_cast<const float4*>(g.A + off);
+      ra[p * 4] = t.x; ra[p * 4 + 1] = t.y; ra[p * 4 + 2] = t.z; ra[p * 4 + 3] = t.w;
+      if (GATE) {
+        const float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
+        rg[p * 4] = q.x; rg[p * 4 + 1] = q.y; rg[p * 4 + 2] = q.z; rg[p * 4 + 3] = q.w;
+      }
+      mbvae_row_mask_bytes(g.mask, g.a_mask_mode, row, g.n_nodes, ma[p], mb[p]);
+    }
+    if (kc == 0 && g.c_mask_mode != MBVAE_MASK_NONE && tid < BM)
+      mbvae_row_mask_bytes(g.mask, mask_mode, m0 + tid, g.n_nodes, ta, tb);
+  };
+  auto commit = [&](int c) {
+    float* dst = As + (c & 1) * BK * LDA;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const float rk = (ma[p] && mb[p]) ? g.a_gate_scale : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = ra[p * 4 + q];
+        if (GATE && !(rg[p * 4 + q] > 0.f)) v = 0.f;
+        if (prologue) v *= rk;
+        dst[((tid & 7) * 4 + q) * LDA + (tid >> 3) + 64 * p] = v;
+      }
+    }
+    const int lt = c / cpt;
+    if (c == lt * cpt && g.c_mask_mode != MBVAE_MASK_NONE && tid < BM) keepS[(lt & 1) * BM + tid] = (ta && tb) ? 1.f : 0.f;
+  };
+
+  float bj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bj[j] = g.bias ? g.bias[(wn * TN + j) * 32 + r] : 0.f;
+
+  if (total > 0) fetch(0);
+  for (int c = 0; c < total; ++c) {
+    commit(c);
+    __syncthreads();
+    if (c + 1 < total) fetch(c + 1);
+    const float* Ab = As + (c & 1) * BK * LDA;
+    const int lt = c / cpt, kc = (c - lt * cpt) * BK;
+#pragma unroll 4
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ab[(2 * kk + h) * LDA + (wm * TM + i) * 32 + r];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(kc + 2 * kk + h) * LDB + (wn * TN + j) * 32 + r];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + BK == K) {                            // tile finished: epilogue, then restart the accumulators
+      const int m0 = ((int)blockIdx.x + lt * (int)gridDim.x) * BM;
+      const float* ks = keepS + (lt & 1) * BM;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float keep[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          keep[v] = g.c_mask_mode == MBVAE_MASK_NONE ? 1.f : ks[(wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + r;
+            float o = acc[i][j][v] + bj[j];
+            if (g.act == 1) o = fmaxf(o, 0.f);
+            if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
+            o *= keep[v];
+            if (g.accumulate) o += g.C[(int64_t)row * g.ldc + col];
+            g.C[(int64_t)row * g.ldc + col] = o;
+            acc[i][j][v] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+static int ts_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+// returns MBVAE_EUNSUPPORTED when the shape does not qualify (the caller then uses the generic kernel)
+template <bool B_KC>
+static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
+  if (getenv("MBVAE_NO_TSGEMM")) return MBVAE_EUNSUPPORTED;
+  const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0;
+  if (!aligned || g.M < 32768 || g.K % 32 || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
+  if (g.N != 128 && g.N != 256 && !(g.N == 64 && getenv("MBVAE_TSGEMM_N64"))) return MBVAE_EUNSUPPORTED;
+  const int BM = g.N == 256 ? 128 : 256;
+  if (g.M % BM) return MBVAE_EUNSUPPORTED;
+  const size_t smem = sizeof(float) * ((size_t)g.K * (g.N + 1) + 2 * 32 * (BM + 1) + 2 * BM);
+  const int grid = std::min(g.M / BM, ts_num_cus());
+  const bool gate = g.a_gate != nullptr;
+#define TS_LAUNCH(n, bm, wm, wn)                                                                                     \
+  do {                                                                                                                \
+    auto kg = tsgemm_kernel<n, bm, wm, wn, B_KC, true>;                                                               \
+    auto kn = tsgemm_kernel<n, bm, wm, wn, B_KC, false>;                                                              \
+    auto k = gate ? kg : kn;                                                                                          \
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
+      return MBVAE_ELAUNCH;                                                                                           \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g);                                                    \
+  } while (0)
+  if (g.N == 256) TS_LAUNCH(256, 128, 2, 4);
+  else if (g.N == 128) TS_LAUNCH(128, 256, 4, 2);
+  else TS_LAUNCH(64, 256, 4, 2);
+#undef TS_LAUNCH
+  return mbvae_launch_status();
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
   if (!g.A || !g.B || !g.C) return MBVAE_EINVAL;
+  if (A_KC) {
+    const int st = tsgemm_try<B_KC>(g, stream);
+    if (st != MBVAE_EUNSUPPORTED) return st;
+  }
   int BM, BN;
   if (g.M <= 64 || g.N <= 32 || (int64_t)g.M * g.N <= 512 * 1024) { BM = 64; BN = 64; }
   else if (g.N <= 64) { BM = 128; BN = 64; }
   else { BM = 128; BN = 128; }
+  if (const char* force = getenv("MBVAE_GEMM_TILE")) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128
+    const int f = atoi(force);
+    BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
+  }
   const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   // split the reduction until ~2 blocks per CU are in flight

@@ -37,6 +37,9 @@ def ragged_mask(bs, n, gen):
     (300, 64, 256, 0, "none"), (1000, 5, 128, 1, "none"), (4 * 9, 13, 24, 1, "node"), (4 * 81, 16, 32, 0, "edge"),
     (2 * 64 * 64, 256, 64, 0, "edge"), (256, 1037, 2048, 1, "none"), (256, 1024, 1024, 0, "none"), (70, 128, 5, 0, "none"),
     (5000, 64, 128, 1, "none"), (33, 4170, 512, 0, "none"),
+    # edge-path shapes that take the persistent resident-weight kernel (M >= 32768, K*N <= 16384)
+    (16 * 64 * 64, 64, 256, 0, "edge"), (16 * 64 * 64, 256, 64, 0, "edge"), (16 * 64 * 64, 64, 128, 1, "none"),
+    (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"),
 ])
 def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     g = torch.Generator().manual_seed(M + K + N)
@@ -49,7 +52,7 @@ def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     if mode == "node":
         n = 9; mask = ragged_mask(M // n, n, g); mm = ops.MASK_NODE; keep = mask.reshape(M, 1).float()
     elif mode == "edge":
-        n = int(round(math.sqrt(M // (4 if M == 4 * 81 else 2)))); bs = M // (n * n)
+        n = 9 if M == 4 * 81 else 64; bs = M // (n * n)
         mask = ragged_mask(bs, n, g); mm = ops.MASK_EDGE
         keep = (mask.unsqueeze(1) & mask.unsqueeze(2)).reshape(M, 1).float()
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))

@@ -17,7 +17,10 @@ def timeit(fn, iters=10):
 bs, n = 256, 64
 M = bs * n * n
 mask = torch.ones(bs, n, dtype=torch.bool, device="cuda")
-for K, N in ((64, 256), (256, 64), (64, 128), (128, 64)):
+shapes = ((64, 256), (256, 64), (64, 128), (128, 64))
+if len(sys.argv) > 2:
+    shapes = ((int(sys.argv[1]), int(sys.argv[2])),)
+for K, N in shapes:
     x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
     dy = torch.randn(M, N, device="cuda")
     for mode, mm in (("none", None), ("edge", mask)):
