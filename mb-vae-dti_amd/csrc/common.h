@@ -47,16 +47,21 @@ __device__ __forceinline__ float mbvae_row_keep(const uint8_t* mask, int mode, i
   return (mask[bi] && mask[b * un + j]) ? 1.f : 0.f;
 }
 
-// Raw mask bytes deciding whether row r survives (both must be non-zero).  Lets a kernel issue the loads early and
-// combine them later, so that no arithmetic waits on them at the issue point.
-__device__ __forceinline__ void mbvae_row_mask_bytes(const uint8_t* mask, int mode, int64_t r, int n, uint8_t& a, uint8_t& b) {
-  a = 1; b = 1;
-  if (mode == MBVAE_MASK_NODE) { a = mask[r]; return; }
-  if (mode == MBVAE_MASK_EDGE) {
-    const unsigned un = (unsigned)n, ur = (unsigned)r;
-    const unsigned bi = ur / un, j = ur - bi * un, bb = bi / un;
-    a = mask[bi]; b = mask[bb * un + j];
-  }
+// Raw mask values deciding whether row r survives (both must be non-zero).  Lets a kernel issue the loads early and
+// combine them later.  The outputs are full 32-bit registers and the index selection is branch-free on purpose: byte
+// variables get packed by the compiler, which consumes (and therefore waits for) each load right where it is issued
+// and serialises every other load in flight behind it.
+__device__ __forceinline__ void mbvae_row_mask_bytes(const uint8_t* mask, int mode, int64_t r, int n, const void* safe,
+                                                     unsigned& a, unsigned& b) {
+  // `safe` is any readable address: with no mask the two loads still execute (from there) and are overridden, which
+  // keeps this function free of control flow.
+  const bool none = mode == MBVAE_MASK_NONE;
+  const uint8_t* mp = none ? reinterpret_cast<const uint8_t*>(safe) : mask;
+  const unsigned un = none ? 1u : (unsigned)n, ur = (unsigned)r;
+  const unsigned bi = ur / un, j = ur - bi * un, bb = bi / un;
+  const unsigned ia = none ? 0u : (mode == MBVAE_MASK_EDGE ? bi : ur);
+  const unsigned ib = none ? 0u : (mode == MBVAE_MASK_EDGE ? bb * un + j : ur);
+  a = mp[ia] | (unsigned)none; b = mp[ib] | (unsigned)none;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

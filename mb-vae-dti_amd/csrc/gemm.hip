@@ -204,12 +204,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   };
 
   const bool want_colsum = (g.colsum != nullptr || g.partial_colsum != nullptr) && n0 == 0;
+  // The prefetch is unconditional (past the end it re-reads the last tile, which is never committed): loads issued
+  // under a branch make the compiler wait for them at the join, i.e. before the MFMA loop they should overlap.
+  const int klast = kbeg + (max(kend - kbeg, 1) - 1) / BK * BK;
   if (kbeg < kend) fetch(kbeg);
   for (int kt = kbeg; kt < kend; kt += BK) {
     __syncthreads();                 // previous tile fully consumed
     commit(kt);
     __syncthreads();
-    if (kt + BK < kend) fetch(kt + BK);
+    fetch(min(kt + BK, klast));
     if (want_colsum && tid < BM) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) colsum += As[k * LDAS + tid];
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
   }
 
   float ra[PASSES * 4], rg[PASSES * 4];
-  uint8_t ma[PASSES], mb[PASSES], ta = 1, tb = 1;     // raw mask bytes: rows of the staged chunk / this thread's tile row
+  unsigned ma[PASSES], mb[PASSES], ta = 1, tb = 1;     // raw mask bytes: rows of the staged chunk / this thread's tile row
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -353,10 +356,9 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
         const float4 q = *reinterpret_cast<const float4*>(g.a_gate + off);
         rg[p * 4] = q.x; rg[p * 4 + 1] = q.y; rg[p * 4 + 2] = q.z; rg[p * 4 + 3] = q.w;
       }
-      mbvae_row_mask_bytes(g.mask, g.a_mask_mode, row, g.n_nodes, ma[p], mb[p]);
+      mbvae_row_mask_bytes(g.mask, g.a_mask_mode, row, g.n_nodes, g.A, ma[p], mb[p]);
     }
-    if (kc == 0 && g.c_mask_mode != MBVAE_MASK_NONE && tid < BM)
-      mbvae_row_mask_bytes(g.mask, mask_mode, m0 + tid, g.n_nodes, ta, tb);
+    mbvae_row_mask_bytes(g.mask, mask_mode, m0 + min(tid, BM - 1), g.n_nodes, g.A, ta, tb);   // this thread's tile row
   };
   auto commit = [&](int c) {
     float* dst = As + (c & 1) * BK * LDA;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
   for (int c = 0; c < total; ++c) {
     commit(c);
     __syncthreads();
-    if (c + 1 < total) fetch(c + 1);
+    fetch(min(c + 1, total - 1));                  // unconditional: a branch here would make the loads wait at its join
     const float* Ab = As + (c & 1) * BK * LDA;
     const int lt = c / cpt, kc = (c - lt * cpt) * BK;
 #pragma unroll 4
@@ -467,12 +469,215 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   return mbvae_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent weight gradient for the edge path: dW[P,Q] = pro(dY)[R,P]^T @ X[R,Q] with R ~ 10^6 rows and an output
+// small enough (P*Q <= 16384) that ONE workgroup holds all of it in MFMA accumulators.  Every row of dY and X is then
+// read from HBM exactly once (an output-tiled kernel re-reads each operand once per tile of the other).  One
+// 512-thread workgroup per CU walks over 32-row chunks dealt round-robin; both operands are row-contiguous, so chunks
+// are copied into LDS as they are (k-major for the MFMA fetch).  Two chunks are in flight in registers (40 KB per CU
+// at P+Q = 320) underneath the MFMA stream, which is what keeps HBM busy with a single workgroup per CU.  Each
+// workgroup writes its partial dW (and partial column sums of pro(dY), the bias gradient) to the workspace; a second
+// kernel adds the partials in a fixed order, so results are bitwise reproducible.
+template <int P, int Q, int WM, int WN, bool GATE>
+__global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
+  constexpr int BR = 32;
+  constexpr int TM = P / (32 * WM), TN = Q / (32 * WN);
+  constexpr int LDA = P + 4, LDB = Q + 4;
+  constexpr int NA = P / 64, NB = Q / 64;          // float4 per thread per chunk
+  constexpr int RGA = 2048 / P, RGB = 2048 / Q;    // rows covered by one pass of the 512 threads
+  static_assert(WM * WN == 8 && TM >= 1 && TN >= 1 && NA >= 1 && NB >= 1, "8 waves, 64 <= P,Q");
+  extern __shared__ __align__(16) float tw_smem[];
+  float* As = tw_smem;                             // [2][BR][LDA]
+  float* Bs = As + 2 * BR * LDA;                   // [2][BR][LDB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+  const int my = (nchunks - bx + G - 1) / G;
+  const int arow = tid / (P / 4), ac4 = (tid % (P / 4)) * 4;
+  const int brow = tid / (Q / 4), bc4 = (tid % (Q / 4)) * 4;
+
+  float4 ra[2][NA], rg[2][NA];
+  float rb[2][NB * 4];     // scalars: a float4 array that is only copied (never modified) stays in scratch memory
+  unsigned ma[2][NA], mb[2][NA];
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // Every step of the main loop is unconditional (no loads or LDS writes under a branch): a chunk index past the end
+  // is clamped to the last chunk and its rows are scaled by zero, so the staged registers have one definition per
+  // step and the compiler can leave the loads in flight until the commit one step later.
+  float vld[2];
+#define TW_FETCH(c, S)                                                                                \
+  {                                                                                                   \
+    const int cc = min((c), my - 1);                                                                   \
+    vld[S] = (c) < my ? g.a_gate_scale : 0.f;                                                          \
+    const int64_t m0 = (int64_t)(bx + cc * G) * BR;                                                    \
+    _Pragma("unroll") for (int p = 0; p < NA; ++p) {                                                   \
+      const int64_t row = m0 + arow + RGA * p;                                                         \
+      ra[S][p] = *reinterpret_cast<const float4*>(g.A + row * g.lda + ac4);                            \
+      if (GATE) rg[S][p] = *reinterpret_cast<const float4*>(g.a_gate + row * g.lda + ac4);             \
+      mbvae_row_mask_bytes(g.mask, g.a_mask_mode, row, g.n_nodes, g.A, ma[S][p], mb[S][p]);             \
+    }                                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < NB; ++p) {                                                   \
+      const float4 t = *reinterpret_cast<const float4*>(g.B + (m0 + brow + RGB * p) * g.ldb + bc4);    \
+      rb[S][4 * p] = t.x; rb[S][4 * p + 1] = t.y; rb[S][4 * p + 2] = t.z; rb[S][4 * p + 3] = t.w;      \
+    }                                                                                                  \
+  }
+#define TW_COMMIT(c, S)                                                                               \
+  {                                                                                                   \
+    float* da = As + ((c) & 1) * BR * LDA;                                                             \
+    float* db = Bs + ((c) & 1) * BR * LDB;                                                             \
+    _Pragma("unroll") for (int p = 0; p < NA; ++p) {                                                   \
+      float4 v = ra[S][p];                                                                             \
+      if (GATE) {                                                                                      \
+        if (!(rg[S][p].x > 0.f)) v.x = 0.f;                                                            \
+        if (!(rg[S][p].y > 0.f)) v.y = 0.f;                                                            \
+        if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                            \
+        if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                            \
+      }                                                                                                \
+      const float rk = (ma[S][p] && mb[S][p]) ? vld[S] : 0.f;                                          \
+      v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                      \
+      cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;                                              \
+      *reinterpret_cast<float4*>(da + (arow + RGA * p) * LDA + ac4) = v;                               \
+    }                                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < NB; ++p) {                                                   \
+      *reinterpret_cast<float4*>(db + (brow + RGB * p) * LDB + bc4) =                                  \
+          make_float4(rb[S][4 * p], rb[S][4 * p + 1], rb[S][4 * p + 2], rb[S][4 * p + 3]);             \
+    }                                                                                                  \
+  }
+#define TW_STEP(c, S)                                                                                 \
+  {                                                                                                   \
+    TW_FETCH((c) + 2, S)                                                                               \
+    const float* Ab = As + ((c) & 1) * BR * LDA;                                                       \
+    const float* Bb = Bs + ((c) & 1) * BR * LDB;                                                       \
+    _Pragma("unroll 4") for (int kk = 0; kk < BR / 2; ++kk) {                                          \
+      float a[TM], b[TN];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) a[i] = Ab[(2 * kk + h) * LDA + (wm * TM + i) * 32 + r]; \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) b[j] = Bb[(2 * kk + h) * LDB + (wn * TN + j) * 32 + r]; \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);            \
+    }                                                                                                  \
+    TW_COMMIT((c) + 1, 1 - S)                                                                          \
+    __syncthreads();                                                                                   \
+  }
+
+  TW_FETCH(0, 0)
+  TW_FETCH(1, 1)
+  TW_COMMIT(0, 0)
+  __syncthreads();
+  for (int c = 0; c < my; c += 2) {
+    TW_STEP(c, 0)
+    TW_STEP(c + 1, 1)
+  }
+#undef TW_FETCH
+#undef TW_COMMIT
+#undef TW_STEP
+
+  // ---- partial dW of this workgroup
+  float* part = g.partial + (int64_t)bx * P * Q;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) part[row * Q + (wn * TN + j) * 32 + r] = acc[i][j][v];
+    }
+  // ---- partial column sums of pro(dY): threads with equal column group combine through LDS in a fixed order
+  if (g.partial_colsum != nullptr) {
+    float* tmp = As;                                // [512 / (P/4)][P]; the last chunk has been consumed (barrier above)
+    *reinterpret_cast<float4*>(tmp + arow * P + ac4) = cs;
+    __syncthreads();
+    if (tid < P) {
+      float s = 0.f;
+      for (int q = 0; q < RGA; ++q) s += tmp[q * P + tid];
+      g.partial_colsum[(int64_t)bx * P + tid] = s;
+    }
+  }
+}
+
+// Sums `splits` partial [M,N] results (+ partial column sums) in a fixed order: 4 waves per 64 consecutive outputs,
+// wave z adds the partials z, z+4, ..., the four sums are combined through LDS.
+__global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int splits) {
+  __shared__ float part[4][64];
+  const int64_t total = (int64_t)g.M * g.N;
+  const int lane = threadIdx.x & 63, z0 = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < total) {
+#pragma unroll 8
+    for (int z = z0; z < splits; z += 4) s += g.partial[(int64_t)z * total + e];
+  } else if (e < total + g.M && g.colsum) {
+#pragma unroll 8
+    for (int z = z0; z < splits; z += 4) s += g.partial_colsum[(int64_t)z * g.M + (e - total)];
+  }
+  part[z0][lane] = s;
+  __syncthreads();
+  if (z0 == 0) {
+    s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (e < total) {
+      const int row = (int)(e / g.N), col = (int)(e - (int64_t)row * g.N);
+      if (g.accumulate) s += g.C[(int64_t)row * g.ldc + col];
+      g.C[(int64_t)row * g.ldc + col] = s;
+    } else if (e < total + g.M && g.colsum) {
+      g.colsum[e - total] = s;
+    }
+  }
+}
+
+// returns MBVAE_EUNSUPPORTED when the shape does not qualify (the caller then uses the generic kernel)
+static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (getenv("MBVAE_NO_TSWGRAD")) return MBVAE_EUNSUPPORTED;
+  const int P = g.M, Q = g.N, R = g.K;
+  const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
+  if (!aligned || R < 32768 || R % 32 || P * Q > 16384 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
+    return MBVAE_EUNSUPPORTED;
+  const int nchunks = R / 32;
+  const int grid = std::min(nchunks, ts_num_cus());
+  const int64_t need = (int64_t)grid * ((int64_t)P * Q + P) * 4;
+  if (workspace == nullptr || ws_bytes < need) return MBVAE_EUNSUPPORTED;
+  g.partial = (float*)workspace;
+  g.partial_colsum = g.colsum ? g.partial + (int64_t)grid * P * Q : nullptr;
+  const size_t smem = sizeof(float) * 2 * 32 * (size_t)(P + 4 + Q + 4);
+  const bool gate = g.a_gate != nullptr;
+#define TW_LAUNCH(p, q, wm, wn)                                                                                      \
+  do {                                                                                                                \
+    auto kg = tswgrad_kernel<p, q, wm, wn, true>;                                                                     \
+    auto kn = tswgrad_kernel<p, q, wm, wn, false>;                                                                    \
+    auto k = gate ? kg : kn;                                                                                          \
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
+      return MBVAE_ELAUNCH;                                                                                           \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g, nchunks);                                           \
+  } while (0)
+  if (P == 256 && Q == 64) TW_LAUNCH(256, 64, 4, 2);
+  else if (P == 64 && Q == 256) TW_LAUNCH(64, 256, 2, 4);
+  else if (P == 128 && Q == 64) TW_LAUNCH(128, 64, 4, 2);
+  else if (P == 64 && Q == 128) TW_LAUNCH(64, 128, 2, 4);
+  else if (P == 128 && Q == 128) TW_LAUNCH(128, 128, 4, 2);
+  else return MBVAE_EUNSUPPORTED;
+#undef TW_LAUNCH
+  const int64_t total = (int64_t)P * Q + P;
+  hipLaunchKernelGGL(tswgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, g, grid);
+  return mbvae_launch_status();
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
   if (!g.A || !g.B || !g.C) return MBVAE_EINVAL;
   if (A_KC) {
     const int st = tsgemm_try<B_KC>(g, stream);
+    if (st != MBVAE_EUNSUPPORTED) return st;
+  } else if (!B_KC) {
+    const int st = tswgrad_try(g, workspace, ws_bytes, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
   }
   int BM, BN;

@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmbvae_hip.so")
+# MBVAE_LIB selects another build of the same library (kernel A/B timing); the default is the in-tree build.
+LIB_PATH = os.environ.get("MBVAE_LIB") or os.path.join(os.path.dirname(_HERE), "libmbvae_hip.so")
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 

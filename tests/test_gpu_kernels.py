@@ -39,7 +39,7 @@ def ragged_mask(bs, n, gen):
     (5000, 64, 128, 1, "none"), (33, 4170, 512, 0, "none"),
     # edge-path shapes that take the persistent resident-weight kernel (M >= 32768, K*N <= 16384)
     (16 * 64 * 64, 64, 256, 0, "edge"), (16 * 64 * 64, 256, 64, 0, "edge"), (16 * 64 * 64, 64, 128, 1, "none"),
-    (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"),
+    (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"), (16 * 64 * 64, 128, 128, 1, "edge"),
 ])
 def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     g = torch.Generator().manual_seed(M + K + N)

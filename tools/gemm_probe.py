@@ -27,10 +27,13 @@ for K, N in shapes:
         with torch.no_grad():
             t = timeit(lambda: ops.linear(x, w, b, mask=mm, mask_mode=ops.MASK_EDGE, n_nodes=n))
         print(f"fwd  K={K:4d} N={N:4d} mask={mode:5s} {t*1000:8.1f} us  {2*M*K*N/t/1e9:7.1f} TFLOP/s  {(M*K+M*N)*4/t/1e6:7.1f} GB/s", flush=True)
-    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
-    y = ops.linear(xr, wr, b, mask=mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
-    def bw():
-        xr.grad = None; wr.grad = None
-        y.backward(dy, retain_graph=True)
-    t = timeit(bw)
-    print(f"bwd(in+w) K={K:4d} N={N:4d} mask=edge  {t*1000:8.1f} us  {4*M*K*N/t/1e9:7.1f} TFLOP/s", flush=True)
+    from mbvae_amd import _lib
+    ws = ops.workspace(x.device); st = torch.cuda.current_stream().cuda_stream
+    m8 = mask.view(torch.uint8)
+    dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(b)
+    t = timeit(lambda: _lib.call("mbvae_linear_bwd_input", dy.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, 0, 1.0,
+                                 m8.data_ptr(), ops.MASK_EDGE, n, 0, ws.data_ptr(), ws.numel(), st))
+    print(f"dgrad K={K:4d} N={N:4d} mask=edge  {t*1000:8.1f} us  {2*M*K*N/t/1e9:7.1f} TFLOP/s  {(M*K+M*N)*4/t/1e6:7.1f} GB/s", flush=True)
+    t = timeit(lambda: _lib.call("mbvae_linear_bwd_weight", dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, K, N,
+                                 0, 1.0, m8.data_ptr(), ops.MASK_EDGE, n, 0, ws.data_ptr(), ws.numel(), st))
+    print(f"wgrad K={K:4d} N={N:4d} mask=edge  {t*1000:8.1f} us  {2*M*K*N/t/1e9:7.1f} TFLOP/s  {(M*K+M*N)*4/t/1e6:7.1f} GB/s", flush=True)
