@@ -20,14 +20,19 @@ static inline int mbvae_launch_status() {
   return MBVAE_ELAUNCH;
 }
 
-// Counter-based uniform in [0,1): splitmix64 of (seed, element index).  Used for dropout so that
-// the backward pass regenerates the keep-mask instead of storing it.
+// Counter-based uniform in [0,1): a 32-bit integer hash of (seed, element index).  Used for dropout so that the
+// backward pass regenerates the keep-mask instead of storing it.  32-bit on purpose: the epilogues that call this
+// once per output element sit next to the MFMA stream, where 64-bit integer multiplies would make the vector ALU the
+// bottleneck.  The seed and the upper index half (wave-uniform in practice) fold into one word on the scalar unit.
 __device__ __forceinline__ float mbvae_u01(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
+  const uint32_t s = (uint32_t)seed * 0x9E3779B9u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ (uint32_t)(idx >> 32) * 0xC2B2AE3Du;
+  uint32_t x = (uint32_t)idx ^ s;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16; x += s;
+  x ^= x >> 15; x *= 0x2C1B3C6Du;
+  x ^= x >> 13;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
 // keep-scale of one element under dropout p: 0 if dropped, 1/(1-p) if kept.
@@ -53,15 +58,18 @@ __device__ __forceinline__ float mbvae_row_keep(const uint8_t* mask, int mode, i
 // and serialises every other load in flight behind it.
 __device__ __forceinline__ void mbvae_row_mask_bytes(const uint8_t* mask, int mode, int64_t r, int n, const void* safe,
                                                      unsigned& a, unsigned& b) {
-  // `safe` is any readable address: with no mask the two loads still execute (from there) and are overridden, which
-  // keeps this function free of control flow.
+  // `safe` is any readable address: with no mask the two loads still execute (from there) and are ignored by
+  // mbvae_mask_keep(), which keeps this function free of control flow.
   const bool none = mode == MBVAE_MASK_NONE;
   const uint8_t* mp = none ? reinterpret_cast<const uint8_t*>(safe) : mask;
   const unsigned un = none ? 1u : (unsigned)n, ur = (unsigned)r;
   const unsigned bi = ur / un, j = ur - bi * un, bb = bi / un;
   const unsigned ia = none ? 0u : (mode == MBVAE_MASK_EDGE ? bi : ur);
   const unsigned ib = none ? 0u : (mode == MBVAE_MASK_EDGE ? bb * un + j : ur);
-  a = mp[ia] | (unsigned)none; b = mp[ib] | (unsigned)none;
+  a = mp[ia]; b = mp[ib];      // raw: combine with mbvae_mask_keep() where the flag is needed, not here
+}
+__device__ __forceinline__ bool mbvae_mask_keep(int mode, unsigned a, unsigned b) {
+  return mode == MBVAE_MASK_NONE || (a != 0u && b != 0u);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
     float* dst = As + (c & 1) * BK * LDA;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      const float rk = (ma[p] && mb[p]) ? g.a_gate_scale : 0.f;
+      const float rk = mbvae_mask_keep(g.a_mask_mode, ma[p], mb[p]) ? g.a_gate_scale : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v = ra[p * 4 + q];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
       }
     }
     const int lt = c / cpt;
-    if (c == lt * cpt && g.c_mask_mode != MBVAE_MASK_NONE && tid < BM) keepS[(lt & 1) * BM + tid] = (ta && tb) ? 1.f : 0.f;
+    if (c == lt * cpt && g.c_mask_mode != MBVAE_MASK_NONE && tid < BM) keepS[(lt & 1) * BM + tid] = mbvae_mask_keep(mask_mode, ta, tb) ? 1.f : 0.f;
   };
 
   float bj[TN];
@@ -430,6 +430,171 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave-autonomous variant of the tall-skinny product.  The kernel above moves A through LDS, which costs a scatter,
+// a barrier per chunk and - worse - keeps all eight waves of the CU in the same phase: they all multiply, then all
+// store, so the output stores (the larger half of the HBM traffic when N > K) never overlap the MFMA stream.  Here
+// only the weights live in LDS and nothing synchronises after they are staged.  Every wave owns whole tasks of
+// 32 rows x 32*TN columns: lane (m, h) reads 32 consecutive reduction indices of row m (128 B, eight 16-byte loads)
+// straight into the registers that feed the MFMA A operand, and the reduction runs in the permuted order this
+// register layout implies (step s multiplies indices s and 32+s of a 64-wide group; the matching weight rows come
+// from LDS).  Two rules keep the memory pipeline out of the MFMAs' way:
+//  * The hardware counter that orders vector memory operations tops out at 63 and counts stores as well.  A task
+//    therefore stores at most 32*TN/... = 16*TN <= 64 dwords per lane (wider outputs are split into column blocks
+//    handled by neighbouring waves, which re-read the same A rows through L1/L2), so a whole epilogue can be in
+//    flight while the wave already multiplies its next task.
+//  * The wait for a group's operand loads is pinned right after the previous group's MFMAs and BEFORE the epilogue
+//    stores; placed after them it would have to drain the stores first.
+template <int TN, bool B_KC, bool GATE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WAVES;
+  const int N = g.N, LDB = N + 1;
+  extern __shared__ __align__(16) float ts2_smem[];
+  float* Bs = ts2_smem;                            // [K][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int K = g.K;
+  if (B_KC) {
+    for (int e = tid; e < N * K; e += NT) { const int n = e / K, k = e - n * K; Bs[k * LDB + n] = g.B[(int64_t)n * g.ldb + k]; }
+  } else {
+    for (int e = tid; e < N * K; e += NT) { const int k = e / N, n = e - k * N; Bs[k * LDB + n] = g.B[(int64_t)k * g.ldb + n]; }
+  }
+  __syncthreads();
+
+  const int gpt = K / 64;                           // 64-wide reduction groups per task
+  const int cbs = N / (32 * TN);                    // column blocks; consecutive waves share the rows of one tile
+  const int ntasks = (g.M / 32) * cbs;
+  const int wid = (int)blockIdx.x * WAVES + wave, nw = (int)gridDim.x * WAVES;
+  const int my_tasks = (ntasks - wid + nw - 1) / nw;
+  const int total = my_tasks * gpt;                 // groups this wave multiplies
+  if (total <= 0) return;
+  const int mask_mode = g.a_mask_mode | g.c_mask_mode;
+  const bool relu = g.act == 1;
+  const bool drop = g.drop_p > 0.f;
+  const unsigned ldc = (unsigned)g.ldc;
+  const float drop_keep = 1.f / (1.f - g.drop_p);
+
+  float4 ra[2][8], rg[2][8];
+  unsigned ma[2], mb[2];
+  float keepf[2];                                   // row-mask flag of this lane's row in the staged tile
+  float bjr[2][TN];                                 // bias of the task's columns: loaded with the operands, a load in the
+                                                    // epilogue would stall the stores behind a full memory latency
+  const float* biasp = g.bias ? g.bias : g.A;       // any readable address when there is no bias (value ignored)
+  const float has_bias = g.bias ? 1.f : 0.f;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+
+#define TS2_TASK(qq, lt, gi, tile, cb)                                                                \
+    const int lt = (qq) / gpt, gi = (qq) - lt * gpt;                                                   \
+    const int task = wid + lt * nw, tile = task / cbs, cb = task - tile * cbs;
+  // group q of this wave -> task and reduction offset; past the end the last group is re-read and multiplied by zero
+#define TS2_FETCH(q, S)                                                                               \
+  {                                                                                                   \
+    TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
+    const int64_t row = (int64_t)tile * 32 + r;                                                        \
+    const float* src = g.A + row * g.lda + gi * 64 + 32 * h;                                           \
+    mbvae_row_mask_bytes(g.mask, mask_mode, row, g.n_nodes, g.A, ma[S], mb[S]);                        \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) bjr[S][j] = biasp[g.bias ? cb * (32 * TN) + j * 32 + r : 0]; \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = *reinterpret_cast<const float4*>(src + 4 * p); \
+    if (GATE) {                                                                                        \
+      const float* gs = g.a_gate + row * g.lda + gi * 64 + 32 * h;                                     \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) rg[S][p] = *reinterpret_cast<const float4*>(gs + 4 * p); \
+    }                                                                                                  \
+    asm volatile("" : : : "memory");   /* the loads are issued HERE (the scheduler would sink them to their use) */ \
+  }
+  // operand prologue applied in place; the asm pins the wait for the loads at this point
+#define TS2_PREP(q, S)                                                                                \
+  {                                                                                                   \
+    unsigned late;   /* a zero the compiler cannot see through: keeps the mask test (and its wait) down here */ \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late) : : "memory");                                         \
+    keepf[S] = mbvae_mask_keep(mask_mode, ma[S] | late, mb[S] | late) ? 1.f : 0.f;                     \
+    float rk = g.a_mask_mode != MBVAE_MASK_NONE ? keepf[S] * g.a_gate_scale : g.a_gate_scale;          \
+    if ((q) >= total) rk = 0.f;                                                                        \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
+      float4 v = ra[S][p];                                                                             \
+      if (GATE) {                                                                                      \
+        if (!(rg[S][p].x > 0.f)) v.x = 0.f;                                                            \
+        if (!(rg[S][p].y > 0.f)) v.y = 0.f;                                                            \
+        if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                            \
+        if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                            \
+      }                                                                                                \
+      v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                      \
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                      \
+      ra[S][p] = v;                                                                                    \
+    }                                                                                                  \
+  }
+#define TS2_MMA(q, S)                                                                                 \
+  {                                                                                                   \
+    TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
+    const float* Bg = Bs + (gi * 64 + 32 * h) * LDB + cb * (32 * TN) + r;                              \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
+      const float av[4] = {ra[S][p].x, ra[S][p].y, ra[S][p].z, ra[S][p].w};                            \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], Bg[(4 * p + e) * LDB + j * 32], acc[j], 0, 0, 0); \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  // task finished: bias / ReLU / dropout / row mask, stores (32-bit element offsets: checked by the host)
+#define TS2_EPI(q, S)                                                                                 \
+  {                                                                                                   \
+    TS2_TASK((q), lt, gi, tile, cb)                                                                    \
+    if ((q) < total && gi == gpt - 1) {                                                                \
+      const unsigned long long kb = g.c_mask_mode == MBVAE_MASK_NONE ? ~0ull : __ballot(keepf[S] != 0.f); \
+      const unsigned kh = (unsigned)(kb >> (4 * h));   /* bit i: row 4h+i of the tile survives */      \
+      const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;                \
+      float bj[TN];                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bj[j] = bjr[S][j] * has_bias;                     \
+      if (!drop) {                                                                                     \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const bool kr = (kh >> rr) & 1u;                                                             \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
+            float o = acc[j][v] + bj[j];                                                               \
+            if (relu) o = fmaxf(o, 0.f);                                                               \
+            g.C[off0 + (unsigned)rr * ldc + j * 32] = kr ? o : 0.f;                                    \
+            acc[j][v] = 0.f;                                                                           \
+          }                                                                                            \
+        }                                                                                              \
+      } else {                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const bool kr = (kh >> rr) & 1u;                                                             \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
+            const unsigned off = off0 + (unsigned)rr * ldc + j * 32;                                   \
+            float o = acc[j][v] + bj[j];                                                               \
+            if (relu) o = fmaxf(o, 0.f);                                                               \
+            o *= mbvae_u01(g.seed, off) < g.drop_p ? 0.f : drop_keep;                                  \
+            g.C[off] = kr ? o : 0.f;                                                                   \
+            acc[j][v] = 0.f;                                                                           \
+          }                                                                                            \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+
+  TS2_FETCH(0, 0)
+  TS2_PREP(0, 0)
+  for (int q = 0; q < total; q += 2) {
+    TS2_FETCH(q + 1, 1)
+    TS2_MMA(q, 0)
+    TS2_PREP(q + 1, 1)
+    TS2_EPI(q, 0)
+    TS2_FETCH(q + 2, 0)
+    TS2_MMA(q + 1, 1)
+    TS2_PREP(q + 2, 0)
+    TS2_EPI(q + 1, 1)
+  }
+#undef TS2_TASK
+#undef TS2_FETCH
+#undef TS2_PREP
+#undef TS2_MMA
+#undef TS2_EPI
+}
+
 static int ts_num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -446,6 +611,20 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   if (getenv("MBVAE_NO_TSGEMM")) return MBVAE_EUNSUPPORTED;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0;
   if (!aligned || g.M < 32768 || g.K % 32 || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  if (!getenv("MBVAE_NO_TSGEMM2") && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
+      (int64_t)g.M * g.ldc < 0x3fffffff) {
+    const size_t smem2 = sizeof(float) * (size_t)g.K * (g.N + 1);
+    const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
+    // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
+    const bool wide = g.N % 128 == 0 && !g.a_gate;
+    const int waves = 8;
+    void (*k)(GemmArgs);
+    if (wide) k = tsgemm2_kernel<4, B_KC, false, 8>;
+    else k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8> : tsgemm2_kernel<2, B_KC, false, 8>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return MBVAE_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
+    return mbvae_launch_status();
+  }
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && getenv("MBVAE_TSGEMM_N64"))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
@@ -542,7 +721,7 @@ __global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
         if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                            \
         if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                            \
       }                                                                                                \
-      const float rk = (ma[S][p] && mb[S][p]) ? vld[S] : 0.f;                                          \
+      const float rk = mbvae_mask_keep(g.a_mask_mode, ma[S][p], mb[S][p]) ? vld[S] : 0.f;              \
       v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                      \
       cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;                                              \
       *reinterpret_cast<float4*>(da + (arow + RGA * p) * LDA + ac4) = v;                               \
