@@ -48,14 +48,17 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
 
 /* ---- Edge-feature attention ------------------------------------------------------------------------
  * Replaces graph_transformer.py:206-249 (Y = Q*K/sqrt(df); Y*(E1+1)+E2; FiLM by y; per-channel masked
- * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx], E1,E2 [bs,n,n,dx] already
- * masked; ye_add,ye_mul [bs,dx]; mask [bs,n].  P [bs,n,n,dx] is the input of e_out, wV [bs,n,dx],
- * lse [bs,n,dx] (log-sum-exp per query row and channel, kept for backward).  dx % 4 == 0. */
-int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
-                        const float* ye_add, const float* ye_mul, const uint8_t* mask, float* P, float* wV,
-                        float* lse, int64_t bs, int64_t n, int64_t dx, float scale, mbvae_stream_t stream);
-int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
-                        const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+ * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx] with rows ldq floats apart and
+ * E1,E2 [bs,n,n,dx] with rows lde apart, already masked (the strides let them be column blocks of one fused
+ * q|k|v resp. e_mul|e_add projection output); ye_add,ye_mul [bs,dx]; mask [bs,n].  Dense outputs: P [bs,n,n,dx]
+ * is the input of e_out, wV [bs,n,dx], lse [bs,n,dx] (log-sum-exp per query row and channel, kept for backward).
+ * Backward writes dE1,dE2 / dQ,dK,dV with the same strides as their forward counterparts.
+ * dx, ldq, lde % 4 == 0. */
+int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
+                        int64_t lde, const float* ye_add, const float* ye_mul, const uint8_t* mask, float* P,
+                        float* wV, float* lse, int64_t bs, int64_t n, int64_t dx, float scale, mbvae_stream_t stream);
+int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
+                        int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
                         const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK, float* dV,
                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx, float scale,
                         mbvae_stream_t stream);

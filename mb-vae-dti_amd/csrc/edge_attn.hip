@@ -36,13 +36,14 @@ __global__ __launch_bounds__(256) void edge_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ E1, const float* __restrict__ E2,
     const float* __restrict__ ye_add, const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
-    float* __restrict__ P, float* __restrict__ wV, float* __restrict__ lse, int n, int dx, float scale) {
+    float* __restrict__ P, float* __restrict__ wV, float* __restrict__ lse, int n, int dx, float scale,
+    int ldq, int lde) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, i = blockIdx.x * 4 + wave;
   const int c = blockIdx.y * 256 + lane * 4;
   if (i >= n || c >= dx) return;
   const int64_t node = (int64_t)b * n;
-  const float4 q = ld4(Q + (node + i) * dx + c);
+  const float4 q = ld4(Q + (node + i) * ldq + c);
   const float4 ya = ld4(ye_add + (int64_t)b * dx + c);
   float4 ym = ld4(ye_mul + (int64_t)b * dx + c);
   ym.x += 1.f; ym.y += 1.f; ym.z += 1.f; ym.w += 1.f;
@@ -50,12 +51,13 @@ __global__ __launch_bounds__(256) void edge_attn_fwd_kernel(
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   float4 l = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t rowbase = ((node + i) * n) * (int64_t)dx + c;
+  const int64_t erow = ((node + i) * n) * (int64_t)lde + c;
 #pragma unroll 4
   for (int j = 0; j < n; ++j) {
-    const float4 e1 = ld4(E1 + rowbase + (int64_t)j * dx);
-    const float4 e2 = ld4(E2 + rowbase + (int64_t)j * dx);
-    const float4 k = ld4(K + (node + j) * dx + c);
-    const float4 v = ld4(V + (node + j) * dx + c);
+    const float4 e1 = ld4(E1 + erow + (int64_t)j * lde);
+    const float4 e2 = ld4(E2 + erow + (int64_t)j * lde);
+    const float4 k = ld4(K + (node + j) * ldq + c);
+    const float4 v = ld4(V + (node + j) * ldq + c);
     float4 y; F4_OP(y, f4get(qs, _q) * f4get(k, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
     float4 p; F4_OP(p, f4get(ya, _q) + f4get(ym, _q) * f4get(y, _q));
     st4(P + rowbase + (int64_t)j * dx, p);
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     const float* __restrict__ wV, const float* __restrict__ lse,
     const float* __restrict__ dP, const float* __restrict__ dwV,
     float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dQ, float* __restrict__ dK,
-    float* __restrict__ dV, float* __restrict__ dye_add, float* __restrict__ dye_mul, int n, int dx, float scale) {
+    float* __restrict__ dV, float* __restrict__ dye_add, float* __restrict__ dye_mul, int n, int dx, float scale,
+    int ldq, int lde) {
   __shared__ float dq_acc[EA_ROWS * 256];
   __shared__ float dya_acc[256], dym_acc[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     const int j = blockIdx.y * 32 + wave + 16 * jj;
     dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj]; ks[jj] = dk[jj]; ok[jj] = false;
     if (active && j < n) {
-      const float4 k = ld4(K + (node + j) * dx + c);
+      const float4 k = ld4(K + (node + j) * ldq + c);
       F4_OP(ks[jj], f4get(k, _q) * scale);
       ok[jj] = mask[node + j] != 0;
     }
@@ -124,29 +127,31 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
 #pragma unroll 1
       for (int ii = 0; ii < rows; ++ii) {
         const int i = i0 + ii;
-        const float4 q = ld4(Q + (node + i) * dx + c);
+        const float4 q = ld4(Q + (node + i) * ldq + c);
         const float4 ls = ld4(lse + (node + i) * dx + c);
         const float4 wv = ld4(wV + (node + i) * dx + c);
         const float4 dwv = ld4(dwV + (node + i) * dx + c);
         float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
         const int64_t rowbase = ((node + i) * n) * (int64_t)dx + c;
+        const int64_t erow = ((node + i) * n) * (int64_t)lde + c;
 #pragma unroll
         for (int jj = 0; jj < EA_JPW; ++jj) {
           const int j = blockIdx.y * 32 + wave + 16 * jj;
           if (j < n) {
             const int64_t off = rowbase + (int64_t)j * dx;
-            const float4 e1 = ld4(E1 + off);
-            const float4 e2 = ld4(E2 + off);
+            const int64_t eoff = erow + (int64_t)j * lde;
+            const float4 e1 = ld4(E1 + eoff);
+            const float4 e2 = ld4(E2 + eoff);
             const float4 dp = ld4(dP + off);
-            const float4 vj = ld4(V + (node + j) * dx + c);
+            const float4 vj = ld4(V + (node + j) * ldq + c);
             float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));
             float4 y; F4_OP(y, f4get(qk, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
             float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);
             float4 dy; F4_OP(dy, f4get(dp, _q) * f4get(ym, _q) +
                                    f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q)));
             float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));
-            st4(dE1 + off, t);
-            st4(dE2 + off, dy);
+            st4(dE1 + eoff, t);
+            st4(dE2 + eoff, dy);
             float4 g; F4_OP(g, f4get(dy, _q) * (f4get(e1, _q) + 1.f));
             F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));
             F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     __syncthreads();
     for (int t = threadIdx.x; t < rows * 256; t += 1024) {
       const int ii = t >> 8, cc = t & 255;
-      if (cbase + cc < dx) atomicAdd(&dQ[(node + i0 + ii) * dx + cbase + cc], dq_acc[t]);
+      if (cbase + cc < dx) atomicAdd(&dQ[(node + i0 + ii) * ldq + cbase + cc], dq_acc[t]);
     }
     __syncthreads();
   }
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
 #pragma unroll
     for (int jj = 0; jj < EA_JPW; ++jj) {
       const int j = blockIdx.y * 32 + wave + 16 * jj;
-      if (j < n) { st4(dK + (node + j) * dx + c, dk[jj]); st4(dV + (node + j) * dx + c, dv[jj]); }
+      if (j < n) { st4(dK + (node + j) * ldq + c, dk[jj]); st4(dV + (node + j) * ldq + c, dv[jj]); }
     }
     atomicAdd(&dya_acc[lane * 4 + 0], dya.x); atomicAdd(&dya_acc[lane * 4 + 1], dya.y);
     atomicAdd(&dya_acc[lane * 4 + 2], dya.z); atomicAdd(&dya_acc[lane * 4 + 3], dya.w);
@@ -188,43 +193,48 @@ static bool ea_aligned(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" {
 
-// Q,K,V [bs,n,dx] (masked), E1,E2 [bs,n,n,dx] (masked), ye_add,ye_mul [bs,dx], mask [bs,n] (u8)
-// -> P [bs,n,n,dx], wV [bs,n,dx], lse [bs,n,dx].   scale = 1/sqrt(df).
-int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
-                        const float* ye_add, const float* ye_mul, const uint8_t* mask,
+// Q,K,V [bs,n,dx] rows ldq apart (masked), E1,E2 [bs,n,n,dx] rows lde apart (masked), ye_add,ye_mul [bs,dx],
+// mask [bs,n] (u8) -> P [bs,n,n,dx], wV [bs,n,dx], lse [bs,n,dx] (dense).   scale = 1/sqrt(df).
+// The row strides let Q|K|V and E1|E2 be column blocks of one projection output ([bs,n,3dx], [bs,n,n,2dx]).
+int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
+                        int64_t lde, const float* ye_add, const float* ye_mul, const uint8_t* mask,
                         float* P, float* wV, float* lse, int64_t bs, int64_t n, int64_t dx, float scale,
                         hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
+  if (ldq < dx || lde < dx || (ldq & 3) || (lde & 3) || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
   if (bs > 65535 || n > 0x7fffffff / 4) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_add, ye_mul, P, wV, lse};
   for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
   dim3 grid((unsigned)((n + 3) / 4), (unsigned)((dx + 255) / 256), (unsigned)bs);
   hipLaunchKernelGGL(edge_attn_fwd_kernel, grid, dim3(256), 0, stream, Q, K, V, E1, E2, ye_add, ye_mul, mask,
-                     P, wV, lse, (int)n, (int)dx, scale);
+                     P, wV, lse, (int)n, (int)dx, scale, (int)ldq, (int)lde);
   return mbvae_launch_status();
 }
 
-// Gradients of the above given dP [bs,n,n,dx] and dwV [bs,n,dx].
-// Writes dE1,dE2 [bs,n,n,dx], dQ,dK,dV [bs,n,dx], dye_add,dye_mul [bs,dx].
-int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, const float* E1, const float* E2,
-                        const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+// Gradients of the above given dP [bs,n,n,dx] and dwV [bs,n,dx] (dense).
+// Writes dE1,dE2 (rows lde apart, like E1,E2), dQ,dK,dV (rows ldq apart, like Q,K,V), dye_add,dye_mul [bs,dx].
+int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
+                        int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
                         const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
                         float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
                         float scale, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
+  if (ldq < dx || lde < dx || (ldq & 3) || (lde & 3) || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
   if (bs > 65535 || n > 32 * 65535) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};
   for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
-  if (hipMemsetAsync(dQ, 0, sizeof(float) * bs * n * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
+  // dQ is accumulated with float adds; with ldq > dx the gaps between its rows (dK/dV blocks) are zeroed too and
+  // then overwritten by the kernel's plain stores
+  if (hipMemsetAsync(dQ, 0, sizeof(float) * ((bs * n - 1) * ldq + dx), stream) != hipSuccess) return MBVAE_ELAUNCH;
   if (hipMemsetAsync(dye_add, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
   if (hipMemsetAsync(dye_mul, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
   dim3 grid((unsigned)((dx + 255) / 256), (unsigned)((n + 31) / 32), (unsigned)bs);
   hipLaunchKernelGGL(edge_attn_bwd_kernel, grid, dim3(1024), 0, stream, Q, K, V, E1, E2, ye_mul, mask, wV, lse,
-                     dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale);
+                     dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale, (int)ldq, (int)lde);
   return mbvae_launch_status();
 }
 

@@ -610,7 +610,8 @@ template <bool B_KC>
 static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   if (getenv("MBVAE_NO_TSGEMM")) return MBVAE_EUNSUPPORTED;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0;
-  if (!aligned || g.M < 32768 || g.K % 32 || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
+  // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
   if (!getenv("MBVAE_NO_TSGEMM2") && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
       (int64_t)g.M * g.ldc < 0x3fffffff) {
     const size_t smem2 = sizeof(float) * (size_t)g.K * (g.N + 1);
@@ -625,6 +626,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
     return mbvae_launch_status();
   }
+  if (g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && getenv("MBVAE_TSGEMM_N64"))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
@@ -817,8 +819,9 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
   if (getenv("MBVAE_NO_TSWGRAD")) return MBVAE_EUNSUPPORTED;
   const int P = g.M, Q = g.N, R = g.K;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
-  if (!aligned || R < 32768 || R % 32 || P * Q > 16384 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
+  if (!aligned || R < 32768 || R % 32 || P * Q > 32768 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
     return MBVAE_EUNSUPPORTED;
+  if (P * Q > 16384 && !(P == 512 && Q == 64 && !g.a_gate)) return MBVAE_EUNSUPPORTED;
   const int nchunks = R / 32;
   const int grid = std::min(nchunks, ts_num_cus());
   const int64_t need = (int64_t)grid * ((int64_t)P * Q + P) * 4;
@@ -836,7 +839,12 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
       return MBVAE_ELAUNCH;                                                                                           \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g, nchunks);                                           \
   } while (0)
-  if (P == 256 && Q == 64) TW_LAUNCH(256, 64, 4, 2);
+  if (P == 512 && Q == 64) {                       // fused e_mul|e_add projection: 64 accumulator registers per lane
+    auto k = tswgrad_kernel<512, 64, 8, 1, false>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g, nchunks);
+  }
+  else if (P == 256 && Q == 64) TW_LAUNCH(256, 64, 4, 2);
   else if (P == 64 && Q == 256) TW_LAUNCH(64, 256, 2, 4);
   else if (P == 128 && Q == 64) TW_LAUNCH(128, 64, 4, 2);
   else if (P == 64 && Q == 128) TW_LAUNCH(64, 128, 2, 4);

@@ -62,16 +62,27 @@ class NodeEdgeBlock(nn.Module):
         self.x_out, self.e_out = nn.Linear(dx, dx), nn.Linear(dx, de)
         self.y_out = nn.Sequential(nn.Linear(dy, dy), nn.ReLU(), nn.Linear(dy, dy))
 
+    @staticmethod
+    def _fused(x, layers, **kw):
+        """One product for several Linear layers that read the same input: outputs side by side in the last dim.
+        (The concatenated weight is rebuilt from the layers' own parameters every call; autograd splits its gradient.)"""
+        w = torch.cat([l.weight for l in layers], 0)
+        b = torch.cat([l.bias for l in layers], 0)
+        return ops.linear(x, w, b, **kw)
+
     def forward(self, X, E, y, node_mask):
         n = X.shape[1]
+        dx = self.dx
         node = dict(mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
         edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
-        Q, K, V = _lin(self.q, X, **node), _lin(self.k, X, **node), _lin(self.v, X, **node)
-        E1, E2 = _lin(self.e_mul, E, **edge), _lin(self.e_add, E, **edge)
-        P, wV = ops.edge_attention(Q, K, V, E1, E2, _lin(self.y_e_add, y), _lin(self.y_e_mul, y), node_mask, self.n_head)
+        QKV = self._fused(X, (self.q, self.k, self.v), **node)                   # [bs,n,3dx]
+        E12 = self._fused(E, (self.e_mul, self.e_add), **edge)                   # [bs,n,n,2dx]
+        yp = self._fused(y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
+        ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
+        P, wV = ops.edge_attention(QKV, E12, ye_add, ye_mul, node_mask, self.n_head)
         newE = _lin(self.e_out, P, **edge)
-        newX = _lin(self.x_out, _lin(self.y_x_add, y).unsqueeze(1) + (_lin(self.y_x_mul, y).unsqueeze(1) + 1) * wV, **node)
-        new_y = _lin(self.y_y, y) + self.x_y(X) + self.e_y(E)
+        newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
+        new_y = yy + self.x_y(X) + self.e_y(E)
         new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
         return newX, newE, new_y
 

@@ -101,42 +101,49 @@ def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=
 
 # ------------------------------------------------------------------------------------------------ edge attention
 class _EdgeAttention(torch.autograd.Function):
+    """QKV [bs,n,3dx] = q|k|v and E12 [bs,n,n,2dx] = e_mul|e_add projection outputs (column blocks, read in place)."""
+
     @staticmethod
-    def forward(ctx, Q, K, V, E1, E2, ye_add, ye_mul, mask, n_head):
-        Q, K, V, E1, E2, ye_add, ye_mul = (_f32c(t) for t in (Q, K, V, E1, E2, ye_add, ye_mul))
-        bs, n, dx = Q.shape
+    def forward(ctx, QKV, E12, ye_add, ye_mul, mask, n_head):
+        QKV, E12, ye_add, ye_mul = (_f32c(t) for t in (QKV, E12, ye_add, ye_mul))
+        bs, n, dx3 = QKV.shape
+        dx = dx3 // 3
         scale = 1.0 / math.sqrt(dx // n_head)
         m8 = _mask_u8(mask)
-        P = torch.empty_like(E1)
-        wV = torch.empty_like(Q)
-        lse = torch.empty_like(Q)
-        _lib.call("mbvae_edge_attn_fwd", Q.data_ptr(), K.data_ptr(), V.data_ptr(), E1.data_ptr(), E2.data_ptr(),
+        P = torch.empty((bs, n, n, dx), dtype=torch.float32, device=QKV.device)
+        wV = torch.empty((bs, n, dx), dtype=torch.float32, device=QKV.device)
+        lse = torch.empty_like(wV)
+        q, e = QKV.data_ptr(), E12.data_ptr()
+        _lib.call("mbvae_edge_attn_fwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
                   ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
                   bs, n, dx, scale, _stream())
-        ctx.save_for_backward(Q, K, V, E1, E2, ye_mul, m8, wV, lse)
+        ctx.save_for_backward(QKV, E12, ye_mul, m8, wV, lse)
         ctx.scale = scale
         ctx.mark_non_differentiable(lse)
         return P, wV, lse
 
     @staticmethod
     def backward(ctx, dP, dwV, _dlse):
-        Q, K, V, E1, E2, ye_mul, m8, wV, lse = ctx.saved_tensors
-        bs, n, dx = Q.shape
-        dP = _f32c(dP) if dP is not None else torch.zeros_like(E1)
-        dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(Q)
-        dE1, dE2 = torch.empty_like(E1), torch.empty_like(E1)
-        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+        QKV, E12, ye_mul, m8, wV, lse = ctx.saved_tensors
+        bs, n, dx = wV.shape
+        dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=wV.device)
+        dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
+        dE12 = torch.empty_like(E12)
+        dQKV = torch.empty_like(QKV)
         dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
-        _lib.call("mbvae_edge_attn_bwd", Q.data_ptr(), K.data_ptr(), V.data_ptr(), E1.data_ptr(), E2.data_ptr(),
+        q, e, dq, de = QKV.data_ptr(), E12.data_ptr(), dQKV.data_ptr(), dE12.data_ptr()
+        _lib.call("mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
                   ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
-                  dE1.data_ptr(), dE2.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), dya.data_ptr(),
-                  dym.data_ptr(), bs, n, dx, ctx.scale, _stream())
-        return dQ, dK, dV, dE1, dE2, dya, dym, None, None
+                  de, de + 4 * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, ctx.scale,
+                  _stream())
+        return dQKV, dE12, dya, dym, None, None
 
 
-def edge_attention(Q, K, V, E1, E2, ye_add, ye_mul, node_mask, n_head):
-    """(P, wV): P = ye_add + (ye_mul+1)*Y (input of e_out), wV = per-channel-softmax-weighted values."""
-    P, wV, _ = _EdgeAttention.apply(Q, K, V, E1, E2, ye_add, ye_mul, node_mask, n_head)
+def edge_attention(QKV, E12, ye_add, ye_mul, node_mask, n_head):
+    """(P, wV): P = ye_add + (ye_mul+1)*Y (input of e_out), wV = per-channel-softmax-weighted values.
+
+    QKV [bs,n,3dx] holds the q|k|v projections side by side, E12 [bs,n,n,2dx] the e_mul|e_add projections."""
+    P, wV, _ = _EdgeAttention.apply(QKV, E12, ye_add, ye_mul, node_mask, n_head)
     return P, wV
 
 

@@ -40,6 +40,8 @@ def ragged_mask(bs, n, gen):
     # edge-path shapes that take the persistent resident-weight kernel (M >= 32768, K*N <= 16384)
     (16 * 64 * 64, 64, 256, 0, "edge"), (16 * 64 * 64, 256, 64, 0, "edge"), (16 * 64 * 64, 64, 128, 1, "none"),
     (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"), (16 * 64 * 64, 128, 128, 1, "edge"),
+    # fused e_mul|e_add projection and its gradients (weights up to 128 KB resident in LDS)
+    (16 * 64 * 64, 64, 512, 0, "edge"),
 ])
 def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     g = torch.Generator().manual_seed(M + K + N)
@@ -103,12 +105,16 @@ def test_edge_attention(ops, bs, n, dx, H):
     cpu = [t.clone().requires_grad_(True) for t in (Q, K, V, E1, E2, ya, ym)]
     P, wV = O.edge_attention(*cpu, mask, H)
     ((P * cP).sum() + (wV * cW).sum()).backward()
-    gpu = [t.clone().cuda().requires_grad_(True) for t in (Q, K, V, E1, E2, ya, ym)]
-    Pg, wVg = ops.edge_attention(*gpu, mask.cuda(), H)
+    # the kernel reads q|k|v and e_mul|e_add as column blocks of two fused projection outputs
+    QKV = torch.cat((Q, K, V), -1).cuda().requires_grad_(True)
+    E12 = torch.cat((E1, E2), -1).cuda().requires_grad_(True)
+    yag, ymg = (t.clone().cuda().requires_grad_(True) for t in (ya, ym))
+    Pg, wVg = ops.edge_attention(QKV, E12, yag, ymg, mask.cuda(), H)
     ((Pg * cP.cuda()).sum() + (wVg * cW.cuda()).sum()).backward()
     assert_close(Pg, P, what="P"); assert_close(wVg, wV, what="wV")
-    for name, a, b in zip(("dQ", "dK", "dV", "dE1", "dE2", "dye_add", "dye_mul"), gpu, cpu):
-        assert_close(a.grad, b.grad, rtol=2e-5, what=name)
+    got = list(QKV.grad.split(dx, -1)) + list(E12.grad.split(dx, -1)) + [yag.grad, ymg.grad]
+    for name, a, b in zip(("dQ", "dK", "dV", "dE1", "dE2", "dye_add", "dye_mul"), got, cpu):
+        assert_close(a, b.grad, rtol=2e-5, what=name)
 
 
 # ------------------------------------------------------------------------------------------------ residual + LayerNorm

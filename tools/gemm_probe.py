@@ -20,6 +20,9 @@ mask = torch.ones(bs, n, dtype=torch.bool, device="cuda")
 shapes = ((64, 256), (256, 64), (64, 128), (128, 64))
 if len(sys.argv) > 2:
     shapes = ((int(sys.argv[1]), int(sys.argv[2])),)
+if len(sys.argv) > 3:          # K N M n: rows and nodes per graph (M must equal bs*n*n for the edge mask)
+    M = int(sys.argv[3]); n = int(sys.argv[4]); bs = M // (n * n)
+    mask = torch.ones(bs, n, dtype=torch.bool, device="cuda")
 for K, N in shapes:
     x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
     dy = torch.randn(M, N, device="cuda")
