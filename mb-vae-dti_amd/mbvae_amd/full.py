@@ -619,18 +619,10 @@ class FullDTIModel(_Base):
         return PlaceHolder(X=X_s, E=E_s, y=torch.zeros(bs, 0, device=dev)).type_as(drug_embeddings)
 
     @torch.no_grad()
-    def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False):
-        """Reverse diffusion from the limit distribution for T steps.  Returns molecules grouped per embedding
-        (RDKit Mol objects when RDKit is available, else (atom ids, bond ids) tensor pairs)."""
-        if self.phase in ("pretrain_target", "finetune"):
-            return []
+    def _reverse_diffusion(self, drug_embeddings, n_nodes):
+        """T reverse steps from the limit distribution for one dense batch; returns collapsed class ids on the host."""
         dev = drug_embeddings.device
-        n0 = drug_embeddings.size(0)
-        n_nodes = self.nodes_dist.sample_n(n0, dev) if num_nodes is None else num_nodes.to(dev)
-        if num_samples_per_embedding > 1:
-            drug_embeddings = drug_embeddings.repeat_interleave(num_samples_per_embedding, dim=0)
-            n_nodes = n_nodes.repeat_interleave(num_samples_per_embedding)
-        bs = n0 * num_samples_per_embedding
+        bs = drug_embeddings.size(0)
         n_max = int(n_nodes.max().item())
         node_mask = torch.arange(n_max, device=dev).unsqueeze(0) < n_nodes.unsqueeze(1)
         zT = sample_discrete_feature_noise(self.limit_dist, node_mask)
@@ -641,12 +633,37 @@ class FullDTIModel(_Base):
             X, E = z.X, z.E
         final = PlaceHolder(X=X, E=E).mask(node_mask, collapse=True)
         Xc, Ec = final.X.cpu(), final.E.cpu()
-        sizes = n_nodes.cpu().tolist()
-        graphs = [(Xc[i, :k], Ec[i, :k, :k]) for i, k in enumerate(sizes)]
-        if return_graphs:
-            mols = graphs
+        return [(Xc[i, :k], Ec[i, :k, :k]) for i, k in enumerate(n_nodes.cpu().tolist())]
+
+    @torch.no_grad()
+    def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False, size_buckets=1):
+        """Reverse diffusion from the limit distribution for T steps.  Returns molecules grouped per embedding
+        (RDKit Mol objects when RDKit is available, else (atom ids, bond ids) tensor pairs).
+
+        size_buckets > 1 sorts the molecules by size and runs that many equal-count sub-batches, each padded only to
+        its own largest molecule (the dense n x n edge tensors make the cost grow with n_max^2); every molecule is
+        still sampled independently from the same distribution, only the order of the random draws differs.  The
+        default (1) is the reference's single dense batch."""
+        if self.phase in ("pretrain_target", "finetune"):
+            return []
+        dev = drug_embeddings.device
+        n0 = drug_embeddings.size(0)
+        n_nodes = self.nodes_dist.sample_n(n0, dev) if num_nodes is None else num_nodes.to(dev)
+        if num_samples_per_embedding > 1:
+            drug_embeddings = drug_embeddings.repeat_interleave(num_samples_per_embedding, dim=0)
+            n_nodes = n_nodes.repeat_interleave(num_samples_per_embedding)
+        bs = n0 * num_samples_per_embedding
+        if size_buckets <= 1 or bs < 2 * size_buckets:
+            graphs = self._reverse_diffusion(drug_embeddings, n_nodes)
         else:
-            mols = [self._graph_to_mol(a, b) for a, b in graphs]
+            order = torch.argsort(n_nodes, stable=True)
+            graphs = [None] * bs
+            for part in torch.tensor_split(order, size_buckets):
+                if part.numel() == 0:
+                    continue
+                for i, gph in zip(part.tolist(), self._reverse_diffusion(drug_embeddings[part], n_nodes[part])):
+                    graphs[i] = gph
+        mols = graphs if return_graphs else [self._graph_to_mol(a, b) for a, b in graphs]
         k = num_samples_per_embedding
         return [mols[i * k:(i + 1) * k] for i in range(n0)]
 

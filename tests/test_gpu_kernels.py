@@ -424,8 +424,9 @@ def _tiny_full_model(phase, g, seed_sd):
         embedding_dim=emb, hidden_dim=hid, factor=4, n_layers=2, activation="relu", dropout=0.1, bias=True,
         encoder_type="transformer", aggregator_type="attentive", diffusion_steps=500, sample_every_val=5,
         val_samples_per_embedding=2, test_samples_per_embedding=2, graph_transformer_kwargs=gt, dataset_infos=infos)
-    missing, unexpected = model.load_state_dict(seed_sd, strict=False)
-    assert not missing, f"state_dict keys missing from the reference checkpoint: {missing}"
+    if seed_sd is not None:
+        missing, unexpected = model.load_state_dict(seed_sd, strict=False)
+        assert not missing, f"state_dict keys missing from the reference checkpoint: {missing}"
     return model.cuda()
 
 
@@ -495,9 +496,34 @@ def test_full_model_sampling_and_val_step_run():
             assert atoms.shape == (n,) and bonds.shape == (n, n)
             assert int(atoms.min()) >= 0 and int(atoms.max()) < 8 and torch.equal(bonds, bonds.T)
             assert int(bonds.diagonal().abs().sum()) == 0 and int(bonds.max()) < 5
+    # size-bucketed sampling: same contract, molecules come back in the caller's order
+    groups = model.sample_batch(emb, num_nodes=torch.tensor([9, 4, 6]), num_samples_per_embedding=2, return_graphs=True,
+                                size_buckets=2)
+    for grp, n in zip(groups, (9, 4, 6)):
+        for atoms, bonds in grp:
+            assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
     mask = g["mask"].bool().cuda()
     batch = {"features": {k: v.cuda() for k, v in g["feat_d"].items()}, "representations": {"smiles": ["C"] * 4},
              "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}
     with torch.no_grad():
         nll = model.validation_step(batch, 0)
     assert torch.isfinite(nll)
+
+
+def test_elbo_terms_golden():
+    """Validation-path ELBO terms of the product model (kl_prior, T * KL of the posteriors) against the reference's
+    values for the same clean / noised graphs and denoiser logits (full.py:569-677 of the reference)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.containers import BatchData, GraphData, PlaceHolder, PredictionData
+    g = load_golden("posterior")
+    model = _tiny_full_model("pretrain_drug", g, None)
+    model.eval()
+    noise = {k: g["n_" + k].cuda() for k in ("t", "beta_t", "alpha_s_bar", "alpha_t_bar")}
+    gd = GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=g["mask"].bool().cuda(), X_t=g["X_t"].cuda(),
+                   E_t=g["E_t"].cuda(), noise_params=noise)
+    bd = BatchData(graph_data=gd)
+    pred = PredictionData(graph_reconstruction=PlaceHolder(X=g["logits_X"].cuda(), E=g["logits_E"].cuda()))
+    with torch.no_grad():
+        assert_close(model.kl_prior(bd), g["kl_prior"], what="kl_prior")
+        assert_close(model.compute_Lt(bd, pred), g["Lt"], rtol=2e-5, what="Lt")
