@@ -527,3 +527,45 @@ def test_elbo_terms_golden():
     with torch.no_grad():
         assert_close(model.kl_prior(bd), g["kl_prior"], what="kl_prior")
         assert_close(model.compute_Lt(bd, pred), g["Lt"], rtol=2e-5, what="Lt")
+
+
+def test_conditional_generator_batched_optimisation_matches_per_latent_loop():
+    """The batched latent optimisation follows, row by row, the reference's one-latent-at-a-time Adam loop
+    (validating/conditioning.py:333-391), and the generation step returns one record per molecule."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.conditioning import ConditionalDrugGenerator
+    g = load_golden("common_step")
+    model = _tiny_full_model("train", g, g["sd"])
+    model.T = 3
+    model.noise_schedule = type(model.noise_schedule)(3).cuda()
+    gen = ConditionalDrugGenerator(model, max_batch_size=8, size_buckets=2)
+    torch.manual_seed(1)
+    targets = gen.process_targets({"FP-ESP": torch.rand(2, 48).round(), "EMB-ESM": torch.randn(2, 40), "EMB-NT": torch.randn(2, 20)})
+    assert targets.shape == (2, 32)
+    lat0, flags = gen.sample_initial_latents(2, 3, reference_fingerprints={"FP-Morgan": torch.rand(5, 64).round(),
+                                                                            "EMB-BiomedGraph": torch.randn(5, 24)})
+    assert lat0.shape == (6, 32) and sorted(flags.view(2, 3).sum(1).tolist()) == [2.0, 2.0]
+    best, meta = gen.optimize_latents_for_interaction(lat0, flags, targets, n_samples_per_target=3, n_optimization_steps=12,
+                                                      learning_rate=0.01)
+    # reference schedule: every latent alone
+    for row in range(6):
+        lat = lat0[row:row + 1].clone().requires_grad_(True)
+        opt = torch.optim.Adam([lat], lr=0.01)
+        best_l, best_s = lat.clone(), float("-inf")
+        for _ in range(12):
+            opt.zero_grad()
+            fused, _ = model.fusion(lat, targets[row // 3:row // 3 + 1])
+            prob = torch.sigmoid(model.dti_head(fused)["Y"])
+            (-prob.mean()).backward()
+            opt.step()
+            if prob.item() > best_s:
+                best_s, best_l = prob.item(), lat.clone().detach()
+        assert abs(best_s - float(meta[row, 3])) < 1e-5
+        assert_close(best[row:row + 1], best_l, rtol=1e-4, what=f"optimised latent {row}")
+        assert int(meta[row, 0]) == row // 3 and int(meta[row, 1]) == row % 3 and float(meta[row, 2]) == float(flags[row])
+    with torch.no_grad():
+        start = torch.sigmoid(model.dti_head(model.fusion(lat0, targets.repeat_interleave(3, 0))[0])["Y"]).mean()
+    assert float(meta[:, 3].mean()) > float(start) - 1e-6
+    res = gen.generate_molecules_batch(best, meta, n_molecules_per_latent=2, return_graphs=True)
+    assert len(res) == 12 and {r["target_idx"] for r in res} == {0, 1} and all(r["molecule"] is not None for r in res)
