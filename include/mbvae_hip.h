@@ -122,6 +122,15 @@ int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float
                          int64_t* Ec, float* Xs, float* Es, float* probX, float* probE, int64_t bs, int64_t n,
                          int64_t cx, int64_t ce, mbvae_stream_t stream);
 
+/* ---- class-id wire format ------------------------------------------------------------------------------
+ * Dense clean graphs from int8 class ids (atoms [bs,n], < 0 = padding; bonds [bs,n,n], 0 = none): the output
+ * convention of to_dense + encode_no_edge (mb_vae_dti/training/diffusion/utils.py:90-120, called from
+ * modules/utils.py:391-426): padded nodes are all-zero rows of X, the diagonal of E is all-zero, every other
+ * pair without a bond - padded pairs included - is class 0, nothing is masked.  Lets a data loader ship
+ * bs*n*(n+1) bytes instead of the one-hot floats. */
+int mbvae_dense_from_ids(const int8_t* atoms, const int8_t* bonds, float* X, float* E, uint8_t* mask, int64_t bs,
+                         int64_t n, int64_t cx, int64_t ce, mbvae_stream_t stream);
+
 /* ---- batched symmetric eigendecomposition (n <= 64) ----------------------------------------------------
  * Replaces torch.linalg.eigh on the graph Laplacians, mb_vae_dti/training/diffusion/augmentation.py:68.
  * A [bs,n,n] symmetric -> W [bs,n] ascending, V [bs,n,n] eigenvectors in columns (signs / degenerate

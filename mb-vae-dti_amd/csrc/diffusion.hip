@@ -149,7 +149,42 @@ __global__ __launch_bounds__(256) void reverse_pairs_kernel(const float* __restr
   for (int c = 0; c < C; ++c) onehot_out[p * C + c] = (valid && c == k) ? 1.f : 0.f;
 }
 
+
+// ---- class-id wire format -> dense one-hot batch --------------------------------------------------------
+// atom ids [bs,n] (int8, < 0 = padding) and bond ids [bs,n,n] (int8: 0 none, 1.. bond types) expand to the dense
+// convention the losses expect: X rows of padded nodes all-zero; E diagonal all-zero; EVERY off-diagonal pair
+// without a bond - pairs that touch padding included - is class 0; nothing is masked.
+__global__ void dense_nodes_kernel(const int8_t* __restrict__ atoms, float* __restrict__ X, uint8_t* __restrict__ mask,
+                                   int64_t nodes, int cx) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nodes) return;
+  const int a = atoms[r];
+  mask[r] = a >= 0 ? 1 : 0;
+  for (int c = 0; c < cx; ++c) X[r * cx + c] = (c == a) ? 1.f : 0.f;
+}
+__global__ void dense_pairs_kernel(const int8_t* __restrict__ bonds, float* __restrict__ E, int64_t pairs, int n, int ce) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= pairs) return;
+  const unsigned ij = (unsigned)(r % ((int64_t)n * n));
+  const bool diag = (ij / (unsigned)n) == (ij % (unsigned)n);
+  int b = bonds[r];
+  if (b < 0 || b >= ce) b = 0;
+  for (int c = 0; c < ce; ++c) E[r * ce + c] = (!diag && c == b) ? 1.f : 0.f;
+}
+
 extern "C" {
+
+// Dense clean graphs from class ids: X [bs,n,cx], E [bs,n,n,ce] one-hot floats, mask [bs,n] (u8).
+int mbvae_dense_from_ids(const int8_t* atoms, const int8_t* bonds, float* X, float* E, uint8_t* mask, int64_t bs, int64_t n,
+                         int64_t cx, int64_t ce, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!atoms || !bonds || !X || !E || !mask) return MBVAE_EINVAL;
+  if (bs <= 0 || n <= 0 || cx <= 0 || ce <= 0 || cx > 127 || ce > 127 || n > 46340) return MBVAE_EUNSUPPORTED;
+  const int64_t nodes = bs * n, pairs = bs * n * n;
+  hipLaunchKernelGGL(dense_nodes_kernel, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, stream, atoms, X, mask, nodes, (int)cx);
+  hipLaunchKernelGGL(dense_pairs_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, bonds, E, pairs, (int)n, (int)ce);
+  return mbvae_launch_status();
+}
 
 // Forward noising of one batch: X0 [bs,n,cx], E0 [bs,n,n,ce] one-hot floats, abar_t [bs], marginals, Exp(1) draws.
 // Outputs int64 class ids (E symmetric, zero diagonal) and masked one-hot floats.

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mbvae_kl_reparam_fwd": [_P, _P, _P, _P, _P, _L, _P, _L, _P],
     "mbvae_kl_reparam_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P],
     "mbvae_sym_eig": [_P, _P, _P, _L, _L, _P],
+    "mbvae_dense_from_ids": [_P] * 5 + [_L, _L, _L, _L, _P],
     "mbvae_apply_noise": [_P] * 12 + [_L, _L, _L, _L, _P],
     "mbvae_reverse_sample": [_P] * 18 + [_L, _L, _L, _L, _P],
 }

@@ -357,13 +357,18 @@ class FullDTIModel(_Base):
         return ({k: y[k].squeeze(-1) for k in names}, {k: y[f"{k}_mask"].squeeze(-1) for k in names[1:]})
 
     def _extract_graph_data(self, batch):
-        """Dense clean graph from batch['drug']['G'] / batch['G'] (any object with x, edge_index, edge_attr, batch),
-        or a ready GraphData under the same key.  X and E are not masked; node_mask is returned alongside."""
+        """Dense clean graph from batch['drug']['G'] / batch['G']: any object with x, edge_index, edge_attr, batch
+        (PyG style), a ready GraphData, or {'atom_ids': int8 [bs,n], 'bond_ids': int8 [bs,n,n]} class ids.
+        X and E are not masked; node_mask is returned alongside."""
         G = batch["drug"]["G"] if "drug" in batch and "G" in batch["drug"] else batch.get("G")
         if G is None:
             raise ValueError("No graph data found in batch")
         if isinstance(G, GraphData):
             return G
+        if isinstance(G, dict) and "atom_ids" in G:      # compact wire format: int8 class ids, expanded on the device
+            X, E, node_mask = ops.dense_from_ids(G["atom_ids"].to(self.device), G["bond_ids"].to(self.device),
+                                                 len(self.atom_types), self.limit_dist.E.numel())
+            return GraphData(X=X, E=E, node_mask=node_mask)
         dense, node_mask = to_dense(G.x, G.edge_index, G.edge_attr, G.batch)
         return GraphData(pyg_batch=G, X=dense.X, E=dense.E, node_mask=node_mask)
 

@@ -332,6 +332,24 @@ def sym_eig(A):
     return W, V
 
 
+# ------------------------------------------------------------------------------------------------ class-id wire format
+@torch.no_grad()
+def dense_from_ids(atom_ids, bond_ids, cx, ce):
+    """int8 class ids (atoms [bs,n], < 0 = padding; bonds [bs,n,n], 0 = none) -> (X one-hot [bs,n,cx],
+    E one-hot [bs,n,n,ce], node_mask bool [bs,n]) in the dense-batch convention (unmasked, class 0 on every
+    bond-less off-diagonal pair, zero diagonal)."""
+    if not atom_ids.is_cuda or atom_ids.dtype != torch.int8 or bond_ids.dtype != torch.int8:
+        raise RuntimeError("dense_from_ids: expected int8 class-id tensors on the GPU; the HIP path has no CPU fallback")
+    atom_ids, bond_ids = atom_ids.contiguous(), bond_ids.contiguous()
+    bs, n = atom_ids.shape
+    X = torch.empty((bs, n, cx), dtype=torch.float32, device=atom_ids.device)
+    E = torch.empty((bs, n, n, ce), dtype=torch.float32, device=atom_ids.device)
+    mask = torch.empty((bs, n), dtype=torch.uint8, device=atom_ids.device)
+    _lib.call("mbvae_dense_from_ids", atom_ids.data_ptr(), bond_ids.data_ptr(), X.data_ptr(), E.data_ptr(), mask.data_ptr(),
+              bs, n, cx, ce, _stream())
+    return X, E, mask.view(torch.bool)
+
+
 # ------------------------------------------------------------------------------------------------ diffusion samplers
 @torch.no_grad()
 def apply_noise(X0, E0, node_mask, abar_t, mx, me, expX, expE):

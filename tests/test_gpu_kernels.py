@@ -569,3 +569,30 @@ def test_conditional_generator_batched_optimisation_matches_per_latent_loop():
     assert float(meta[:, 3].mean()) > float(start) - 1e-6
     res = gen.generate_molecules_batch(best, meta, n_molecules_per_latent=2, return_graphs=True)
     assert len(res) == 12 and {r["target_idx"] for r in res} == {0, 1} and all(r["molecule"] is not None for r in res)
+
+
+def test_dense_from_ids_matches_to_dense_convention(ops):
+    """The int8 class-id wire format expands to exactly what to_dense + encode_no_edge build from the sparse batch
+    (padded pairs are class 0, diagonal zero, X rows of padding zero, nothing masked)."""
+    from mbvae_amd.full import to_dense
+    g = torch.Generator().manual_seed(5)
+    sizes, cx, nb = [7, 3, 9, 1], 8, 4
+    xs, ei, ea, bt, off = [], [], [], [], 0
+    n = max(sizes)
+    atom_ids = torch.full((len(sizes), n), -1, dtype=torch.int8)
+    bond_ids = torch.zeros((len(sizes), n, n), dtype=torch.int8)
+    for b, k in enumerate(sizes):
+        a = torch.randint(0, cx, (k,), generator=g)
+        atom_ids[b, :k] = a.to(torch.int8)
+        xs.append(F.one_hot(a, cx).float()); bt.append(torch.full((k,), b))
+        for i in range(k):
+            for j in range(i + 1, k):
+                if torch.rand((), generator=g) < 0.4:
+                    t = int(torch.randint(1, nb + 1, (), generator=g))
+                    bond_ids[b, i, j] = bond_ids[b, j, i] = t
+                    ei += [[off + i, off + j], [off + j, off + i]]
+                    ea += [F.one_hot(torch.tensor(t - 1), nb).float()] * 2
+        off += k
+    dense, mask = to_dense(torch.cat(xs), torch.tensor(ei).T.contiguous(), torch.stack(ea), torch.cat(bt))
+    X, E, m = ops.dense_from_ids(atom_ids.cuda(), bond_ids.cuda(), cx, nb + 1)
+    assert torch.equal(m.cpu(), mask) and torch.equal(X.cpu(), dense.X) and torch.equal(E.cpu(), dense.E)
