@@ -596,3 +596,41 @@ def test_dense_from_ids_matches_to_dense_convention(ops):
     dense, mask = to_dense(torch.cat(xs), torch.tensor(ei).T.contiguous(), torch.stack(ea), torch.cat(bt))
     X, E, m = ops.dense_from_ids(atom_ids.cuda(), bond_ids.cuda(), cx, nb + 1)
     assert torch.equal(m.cpu(), mask) and torch.equal(X.cpu(), dense.X) and torch.equal(E.cpu(), dense.E)
+
+
+def test_denoiser_full_size_properties():
+    """Size-independent properties of the 8-layer denoiser at the benchmark widths (bs*n*n = 65 536 edge rows, so the
+    persistent tall-skinny kernels run): node-permutation equivariance, symmetric / zero-diagonal / masked edge
+    logits, masked node logits, and batch independence (a graph's outputs do not depend on its batch mates)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.graph_transformer import GraphTransformer
+    from mbvae_amd.trainstep import CFG3, synthetic_graphs
+    torch.manual_seed(3)
+    net = GraphTransformer(**CFG3).cuda().eval()
+    g = torch.Generator().manual_seed(11)
+    bs, n = 16, 64
+    sizes = torch.randint(20, n + 1, (bs,), generator=g); sizes[0] = n
+    X0, E0, mask = synthetic_graphs(bs, n, "cuda", g, sizes=sizes)
+    X = torch.cat((X0, torch.randn(bs, n, 8, generator=g).cuda() * mask.unsqueeze(-1)), -1)
+    y = torch.randn(bs, 1037, generator=g).cuda()
+    with torch.no_grad():
+        out = net(X, E0, y, mask)
+        assert float((out.E - out.E.transpose(1, 2)).abs().max()) == 0.0
+        assert float(torch.diagonal(out.E, dim1=1, dim2=2).abs().max()) == 0.0
+        pair = mask.unsqueeze(1) & mask.unsqueeze(2)
+        assert float(out.E[~pair].abs().max()) == 0.0 and float(out.X[~mask].abs().max()) == 0.0
+        assert bool(torch.isfinite(out.X).all() and torch.isfinite(out.E).all() and torch.isfinite(out.y).all())
+        # permute the nodes of every graph (valid nodes among themselves, padding stays behind them)
+        perm = torch.stack([torch.cat((torch.randperm(int(k), generator=g), torch.arange(int(k), n))) for k in sizes]).cuda()
+        bi = torch.arange(bs, device="cuda").unsqueeze(1)
+        Xp = X[bi, perm]
+        Ep = E0[bi.unsqueeze(2), perm.unsqueeze(2), perm.unsqueeze(1)]
+        outp = net(Xp, Ep, y, mask)
+        assert_close(outp.X, out.X[bi, perm], rtol=5e-5, what="permuted X")
+        assert_close(outp.E, out.E[bi.unsqueeze(2), perm.unsqueeze(2), perm.unsqueeze(1)], rtol=5e-5, what="permuted E")
+        assert_close(outp.y, out.y, rtol=5e-5, what="permuted y")
+        # batch independence: the first 9 graphs alone (36 864 edge rows, still on the persistent kernels)
+        sub = net(X[:9], E0[:9], y[:9], mask[:9])
+        assert_close(sub.X, out.X[:9], rtol=2e-5, what="sub-batch X"); assert_close(sub.E, out.E[:9], rtol=2e-5, what="sub-batch E")
+        assert_close(sub.y, out.y[:9], rtol=2e-5, what="sub-batch y")
