@@ -75,16 +75,26 @@ class ExtraFeatures:
 class ExtraMolecularFeatures:
     def __init__(self, valencies, max_weight, atom_weights):
         self.valencies, self.max_weight, self.atom_weights = list(valencies), max_weight, list(atom_weights)
+        self._const = {}
+
+    def _constants(self, dev):
+        """Bond orders / valencies / atomic weights as device tensors, built once per device (a host->device copy
+        per call would synchronise every step and cannot be captured in a HIP graph)."""
+        key = str(dev)
+        if key not in self._const:
+            self._const[key] = (torch.tensor([0, 1, 2, 3, 1.5], device=dev).reshape(1, 1, 1, -1),
+                                torch.tensor(self.valencies, device=dev).reshape(1, 1, -1),
+                                torch.tensor(self.atom_weights, device=dev))
+        return self._const[key]
 
     def __call__(self, X_t, E_t, truncate_weight=False):
         """truncate_weight: the reference's training path hands int64 one-hot tensors to this feature, which makes
         its `.type_as(X_t)` truncate the summed atomic weight to an integer before the division by max_weight;
         the sampling path passes floats and keeps the fraction.  Callers pick the behaviour of the path they mirror."""
-        dev = X_t.device
-        orders = torch.tensor([0, 1, 2, 3, 1.5], device=dev).reshape(1, 1, 1, -1)
+        orders, valencies, weights = self._constants(X_t.device)
         cur = (E_t * orders).argmax(-1).sum(-1)                               # integer "valency" as in the reference
-        normal = (X_t * torch.tensor(self.valencies, device=dev).reshape(1, 1, -1)).argmax(-1)
+        normal = (X_t * valencies).argmax(-1)
         charge = (normal - cur).type_as(X_t)
-        weight = torch.tensor(self.atom_weights, device=dev)[X_t.argmax(-1)].sum(-1, keepdim=True)
+        weight = weights[X_t.argmax(-1)].sum(-1, keepdim=True)
         weight = (torch.trunc(weight) if truncate_weight else weight).type_as(X_t) / self.max_weight
         return torch.stack((charge, cur.type_as(X_t)), -1), weight

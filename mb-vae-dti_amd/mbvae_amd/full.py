@@ -413,7 +413,11 @@ class FullDTIModel(_Base):
 
     # ------------------------------------------------------------------ diffusion
     def _marginals(self, device):
-        return self.limit_dist.X.to(device).float(), self.limit_dist.E.to(device).float()
+        key = str(device)
+        cache = self.__dict__.setdefault("_marginal_cache", {})
+        if key not in cache:                       # one host->device copy per device, not one per step
+            cache[key] = (self.limit_dist.X.to(device).float(), self.limit_dist.E.to(device).float())
+        return cache[key]
 
     def apply_noise(self, X, E, node_mask):
         """t ~ U{0|1..T}, G_t ~ q(G_t | G) through the forward-noising kernel; same RNG draw order as the reference
@@ -624,8 +628,12 @@ class FullDTIModel(_Base):
         return PlaceHolder(X=X_s, E=E_s, y=torch.zeros(bs, 0, device=dev)).type_as(drug_embeddings)
 
     @torch.no_grad()
-    def _reverse_diffusion(self, drug_embeddings, n_nodes):
-        """T reverse steps from the limit distribution for one dense batch; returns collapsed class ids on the host."""
+    def _reverse_diffusion(self, drug_embeddings, n_nodes, use_graph=False):
+        """T reverse steps from the limit distribution for one dense batch; returns collapsed class ids on the host.
+
+        use_graph: capture ONE reverse step (extra features, denoiser forward, posterior + draw; ~350 launches) in a
+        HIP graph and replay it for the remaining T - 1 steps: the step is launch bound for typical molecule sizes.
+        Step times are fed through static device buffers; random draws come from torch's graph-aware generator."""
         dev = drug_embeddings.device
         bs = drug_embeddings.size(0)
         n_max = int(n_nodes.max().item())
@@ -633,22 +641,43 @@ class FullDTIModel(_Base):
         zT = sample_discrete_feature_noise(self.limit_dist, node_mask)
         X, E = zT.X, zT.E
         ones = torch.ones((bs, 1), dtype=self.model_dtype, device=dev)
-        for s_int in reversed(range(self.T)):
-            z = self.sample_p_zs_given_zt(s_int * ones / self.T, (s_int + 1) * ones / self.T, X, E, drug_embeddings, node_mask)
-            X, E = z.X, z.E
+        steps = list(reversed(range(self.T)))
+        if use_graph and len(steps) > 2:
+            emb = drug_embeddings.contiguous()
+            # the first step runs eagerly: it also creates every lazily built buffer (workspace, cached constants)
+            z = self.sample_p_zs_given_zt(steps[0] * ones / self.T, (steps[0] + 1) * ones / self.T, X, E, emb, node_mask)
+            Xb, Eb = z.X.contiguous().clone(), z.E.contiguous().clone()
+            sb, tb = torch.empty_like(ones), torch.empty_like(ones)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                z = self.sample_p_zs_given_zt(sb, tb, Xb, Eb, emb, node_mask)
+                Xb.copy_(z.X)
+                Eb.copy_(z.E)
+            for s_int in steps[1:]:
+                sb.copy_(s_int * ones / self.T)
+                tb.copy_((s_int + 1) * ones / self.T)
+                graph.replay()
+            X, E = Xb, Eb
+        else:
+            for s_int in steps:
+                z = self.sample_p_zs_given_zt(s_int * ones / self.T, (s_int + 1) * ones / self.T, X, E, drug_embeddings, node_mask)
+                X, E = z.X, z.E
         final = PlaceHolder(X=X, E=E).mask(node_mask, collapse=True)
         Xc, Ec = final.X.cpu(), final.E.cpu()
         return [(Xc[i, :k], Ec[i, :k, :k]) for i, k in enumerate(n_nodes.cpu().tolist())]
 
     @torch.no_grad()
-    def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False, size_buckets=1):
+    def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False, size_buckets=1,
+                     use_graph=False):
         """Reverse diffusion from the limit distribution for T steps.  Returns molecules grouped per embedding
         (RDKit Mol objects when RDKit is available, else (atom ids, bond ids) tensor pairs).
 
         size_buckets > 1 sorts the molecules by size and runs that many equal-count sub-batches, each padded only to
         its own largest molecule (the dense n x n edge tensors make the cost grow with n_max^2); every molecule is
         still sampled independently from the same distribution, only the order of the random draws differs.  The
-        default (1) is the reference's single dense batch."""
+        default (1) is the reference's single dense batch.  use_graph replays one captured reverse step as a HIP
+        graph (see _reverse_diffusion)."""
         if self.phase in ("pretrain_target", "finetune"):
             return []
         dev = drug_embeddings.device
@@ -659,14 +688,14 @@ class FullDTIModel(_Base):
             n_nodes = n_nodes.repeat_interleave(num_samples_per_embedding)
         bs = n0 * num_samples_per_embedding
         if size_buckets <= 1 or bs < 2 * size_buckets:
-            graphs = self._reverse_diffusion(drug_embeddings, n_nodes)
+            graphs = self._reverse_diffusion(drug_embeddings, n_nodes, use_graph)
         else:
             order = torch.argsort(n_nodes, stable=True)
             graphs = [None] * bs
             for part in torch.tensor_split(order, size_buckets):
                 if part.numel() == 0:
                     continue
-                for i, gph in zip(part.tolist(), self._reverse_diffusion(drug_embeddings[part], n_nodes[part])):
+                for i, gph in zip(part.tolist(), self._reverse_diffusion(drug_embeddings[part], n_nodes[part], use_graph)):
                     graphs[i] = gph
         mols = graphs if return_graphs else [self._graph_to_mol(a, b) for a, b in graphs]
         k = num_samples_per_embedding

@@ -502,6 +502,13 @@ def test_full_model_sampling_and_val_step_run():
     for grp, n in zip(groups, (9, 4, 6)):
         for atoms, bonds in grp:
             assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
+    # one reverse step captured as a HIP graph and replayed: same contract
+    groups = model.sample_batch(emb, num_nodes=torch.tensor([9, 4, 6]), num_samples_per_embedding=2, return_graphs=True,
+                                use_graph=True)
+    for grp, n in zip(groups, (9, 4, 6)):
+        for atoms, bonds in grp:
+            assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
+            assert int(atoms.min()) >= 0 and int(atoms.max()) < 8 and int(bonds.max()) < 5
     mask = g["mask"].bool().cuda()
     batch = {"features": {k: v.cuda() for k, v in g["feat_d"].items()}, "representations": {"smiles": ["C"] * 4},
              "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}

@@ -20,6 +20,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--nmax", type=int, default=64)
 ap.add_argument("--fixed-n", type=int, default=0, help="all molecules of this size (0: N(28,7) clipped)")
 ap.add_argument("--buckets", type=int, default=1, help="size-sorted sub-batches (sample_batch(size_buckets=...))")
+ap.add_argument("--graph", action="store_true", help="capture one reverse step in a HIP graph and replay it")
 a = ap.parse_args()
 dev = torch.device("cuda")
 cx, emb = 8, 1024
@@ -68,12 +69,25 @@ with torch.no_grad():
 
         run(a.warmup, T - 1)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(a.steps, T - 1 - a.warmup)
+        if a.graph:
+            Xb, Eb = X.contiguous().clone(), E.contiguous().clone()
+            sb, tb = torch.empty_like(ones), torch.empty_like(ones)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model.sample_p_zs_given_zt(sb, tb, Xb, Eb, z, node_mask)
+                Xb.copy_(out.X); Eb.copy_(out.E)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s_int in range(T - 1 - a.warmup, T - 1 - a.warmup - a.steps, -1):
+                sb.copy_(s_int * ones / T); tb.copy_((s_int + 1) * ones / T)
+                graph.replay()
+        else:
+            t0 = time.perf_counter()
+            run(a.steps, T - 1 - a.warmup)
         torch.cuda.synchronize()
         total_ms += 1000 * (time.perf_counter() - t0) / a.steps
 ms = total_ms                     # one reverse step of the whole chunk (all buckets)
 print(json.dumps({"metric": "molecule-steps/sec (reverse diffusion, 8-layer denoiser, fp32)", "value": round(bs / (ms * 1e-3), 1),
-                  "ms_per_step": round(ms, 3), "chunk": bs, "size_buckets": len(parts), "n_max": int(n_nodes.max()),
+                  "ms_per_step": round(ms, 3), "chunk": bs, "size_buckets": len(parts), "hip_graph": bool(a.graph), "n_max": int(n_nodes.max()),
                   "mean_atoms": round(float(n_nodes.float().mean()), 1), "steps_timed": a.steps,
                   "projected_500x10000_s": round(ms * 1e-3 * 500 * 10000 / bs, 1), "data": "synthetic, random-init weights"}))
