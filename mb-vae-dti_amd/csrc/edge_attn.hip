@@ -31,18 +31,30 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
   }
 __device__ __forceinline__ float f4get(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
-// grid: (ceil(n/4), ceil(dx/256), bs), block 256: wave = query row, lane = 4 channels
-__global__ __launch_bounds__(256) void edge_attn_fwd_kernel(
+// grid: (ceil(n/ROWS), ceil(dx/256), bs), block 64*ROWS: wave = query row, lane = 4 channels.
+// STAGE: the graph's K and V rows (n <= 64) are copied to LDS once per block; every query row re-reads all of them,
+// and from global memory they keep getting evicted by the edge streams and fetched again.
+template <int ROWS, bool STAGE>
+__global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ E1, const float* __restrict__ E2,
     const float* __restrict__ ye_add, const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
     float* __restrict__ P, float* __restrict__ wV, float* __restrict__ lse, int n, int dx, float scale,
     int ldq, int lde) {
+  extern __shared__ __align__(16) float kv_rows[];          // STAGE: [2][n][256]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.z, i = blockIdx.x * 4 + wave;
+  const int b = blockIdx.z, i = blockIdx.x * ROWS + wave;
   const int c = blockIdx.y * 256 + lane * 4;
-  if (i >= n || c >= dx) return;
   const int64_t node = (int64_t)b * n;
+  if (STAGE) {
+    if (c < dx)
+      for (int j = wave; j < n; j += ROWS) {
+        st4(&kv_rows[j * 256 + lane * 4], ld4(K + (node + j) * ldq + c));
+        st4(&kv_rows[(n + j) * 256 + lane * 4], ld4(V + (node + j) * ldq + c));
+      }
+    __syncthreads();
+  }
+  if (i >= n || c >= dx) return;
   const float4 q = ld4(Q + (node + i) * ldq + c);
   const float4 ya = ld4(ye_add + (int64_t)b * dx + c);
   float4 ym = ld4(ye_mul + (int64_t)b * dx + c);
@@ -56,8 +68,8 @@ __global__ __launch_bounds__(256) void edge_attn_fwd_kernel(
   for (int j = 0; j < n; ++j) {
     const float4 e1 = ld4(E1 + erow + (int64_t)j * lde);
     const float4 e2 = ld4(E2 + erow + (int64_t)j * lde);
-    const float4 k = ld4(K + (node + j) * ldq + c);
-    const float4 v = ld4(V + (node + j) * ldq + c);
+    const float4 k = STAGE ? ld4(&kv_rows[j * 256 + lane * 4]) : ld4(K + (node + j) * ldq + c);
+    const float4 v = STAGE ? ld4(&kv_rows[(n + j) * 256 + lane * 4]) : ld4(V + (node + j) * ldq + c);
     float4 y; F4_OP(y, f4get(qs, _q) * f4get(k, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
     float4 p; F4_OP(p, f4get(ya, _q) + f4get(ym, _q) * f4get(y, _q));
     st4(P + rowbase + (int64_t)j * dx, p);
@@ -92,6 +104,9 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     int ldq, int lde) {
   __shared__ float dq_acc[EA_ROWS * 256];
   __shared__ float dya_acc[256], dym_acc[256];
+  // V rows of this block's 32 keys: re-read for every query row; from global memory they get evicted from L1/L2 by
+  // the edge streams in between and come back from HBM (measured: +1 GB of fetches per launch)
+  __shared__ __align__(16) float v_rows[32 * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj]; ks[jj] = dk[jj]; ok[jj] = false;
     if (active && j < n) {
       const float4 k = ld4(K + (node + j) * ldq + c);
+      st4(&v_rows[(wave + 16 * jj) * 256 + lane * 4], ld4(V + (node + j) * ldq + c));   // read back by this lane only
       F4_OP(ks[jj], f4get(k, _q) * scale);
       ok[jj] = mask[node + j] != 0;
     }
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
             const float4 e1 = ld4(E1 + eoff);
             const float4 e2 = ld4(E2 + eoff);
             const float4 dp = ld4(dP + off);
-            const float4 vj = ld4(V + (node + j) * ldq + c);
+            const float4 vj = ld4(&v_rows[(wave + 16 * jj) * 256 + lane * 4]);
             float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));
             float4 y; F4_OP(y, f4get(qk, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
             float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);
@@ -203,12 +219,15 @@ int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t 
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
   if (ldq < dx || lde < dx || (ldq & 3) || (lde & 3) || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
-  if (bs > 65535 || n > 0x7fffffff / 4) return MBVAE_EUNSUPPORTED;
+  if (bs > 65535 || n > 0x7fffffff / 16) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_add, ye_mul, P, wV, lse};
   for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
+  // (Staging the graph's K,V rows in LDS - template flag STAGE, 16 query rows per block - brings the measured reads
+  // down to the algorithmic bytes but costs occupancy: 128 KB of LDS leave one block per CU, and the kernel ran 5 %
+  // slower.  The direct version below re-reads K,V through L1/L2 and fetches ~1.18x of its algorithmic bytes.)
   dim3 grid((unsigned)((n + 3) / 4), (unsigned)((dx + 255) / 256), (unsigned)bs);
-  hipLaunchKernelGGL(edge_attn_fwd_kernel, grid, dim3(256), 0, stream, Q, K, V, E1, E2, ye_add, ye_mul, mask,
+  hipLaunchKernelGGL((edge_attn_fwd_kernel<4, false>), grid, dim3(256), 0, stream, Q, K, V, E1, E2, ye_add, ye_mul, mask,
                      P, wV, lse, (int)n, (int)dx, scale, (int)ldq, (int)lde);
   return mbvae_launch_status();
 }
