@@ -871,9 +871,13 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   if (g.M <= 64 || g.N <= 32 || (int64_t)g.M * g.N <= 512 * 1024) { BM = 64; BN = 64; }
   else if (g.N <= 64) { BM = 128; BN = 64; }
   else { BM = 128; BN = 128; }
+  // fewer than two big tiles per CU leave the chip under-filled and every block latency bound: use small tiles
+  if (BM == 128 && (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) < 2 * ts_num_cus()) { BM = 64; BN = 64; }
   if (const char* force = getenv("MBVAE_GEMM_TILE")) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128
-    const int f = atoi(force);
-    BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
+    if (*force) {
+      const int f = atoi(force);
+      BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
+    }
   }
   const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
