@@ -40,6 +40,13 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
                            int64_t K, int64_t N, const float* gate, float gate_scale, const uint8_t* mask,
                            int mask_mode, int n_nodes, int accumulate, void* workspace, int64_t ws_bytes,
                            mbvae_stream_t stream);
+/* dx[M,K] = pro(dy)[M,N] @ w[N,K] + addend[M,K]: the input gradient of a Linear layer whose input also feeds other
+ * consumers (graph_transformer.py:114-146, 187-267: the edge tensor E goes to e_mul/e_add, Etoy and the residual),
+ * with the other consumers' gradient folded in instead of a separate accumulation pass.  Only [bs*n*n, d] shapes
+ * (M >= 32768, M % 32 == 0, N % 64 == 0, K % 64 == 0, K*N <= 32768); MBVAE_EUNSUPPORTED otherwise. */
+int mbvae_linear_bwd_input_add(const float* dy, int64_t lddy, const float* w, const float* addend, float* dx,
+                               int64_t lddx, int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
+                               const uint8_t* mask, int mask_mode, int n_nodes, mbvae_stream_t stream);
 /* dw[N,K] (+)= pro(dy)[M,N]^T @ x[M,K];  db[N] = column sums of pro(dy) (db may be NULL) */
 int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                             int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,

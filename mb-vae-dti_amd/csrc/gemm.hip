@@ -34,6 +34,8 @@ struct GemmArgs {
   float* colsum;
   // split-K
   int k_per_split; float* partial; float* partial_colsum;
+  // optional addend with C's layout (C = epi(...) + addend): only the wave-autonomous tall-skinny kernel applies it
+  const float* addend;
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col, float keep_row) {
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 //    flight while the wave already multiplies its next task.
 //  * The wait for a group's operand loads is pinned right after the previous group's MFMAs and BEFORE the epilogue
 //    stores; placed after them it would have to drain the stores first.
-template <int TN, bool B_KC, bool GATE, int WAVES>
+template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   constexpr int NT = 64 * WAVES;
   const int N = g.N, LDB = N + 1;
@@ -548,7 +550,22 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
       const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;                \
       float bj[TN];                                                                                    \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) bj[j] = bjr[S][j] * has_bias;                     \
-      if (!drop) {                                                                                     \
+      if (ADD) {                                       /* all addend loads first, then one wait */     \
+        float ad[TN][16];                                                                              \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v)                                                 \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+            ad[j][v] = g.addend[off0 + (unsigned)((v & 3) + 8 * (v >> 2)) * ldc + j * 32];             \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const bool kr = (kh >> rr) & 1u;                                                             \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
+            float o = acc[j][v] + bj[j];                                                               \
+            if (relu) o = fmaxf(o, 0.f);                                                               \
+            g.C[off0 + (unsigned)rr * ldc + j * 32] = (kr ? o : 0.f) + ad[j][v];                       \
+            acc[j][v] = 0.f;                                                                           \
+          }                                                                                            \
+        }                                                                                              \
+      } else if (!drop) {                                                                              \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
@@ -613,20 +630,21 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
   if (!getenv("MBVAE_NO_TSGEMM2") && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
-      (int64_t)g.M * g.ldc < 0x3fffffff) {
+      !(g.addend && g.drop_p > 0.f) && (int64_t)g.M * g.ldc < 0x3fffffff) {
     const size_t smem2 = sizeof(float) * (size_t)g.K * (g.N + 1);
     const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
     // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
-    const bool wide = g.N % 128 == 0 && !g.a_gate;
+    const bool wide = g.N % 128 == 0 && !g.a_gate && !g.addend;
     const int waves = 8;
     void (*k)(GemmArgs);
     if (wide) k = tsgemm2_kernel<4, B_KC, false, 8>;
+    else if (g.addend) k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8, true> : tsgemm2_kernel<2, B_KC, false, 8, true>;
     else k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8> : tsgemm2_kernel<2, B_KC, false, 8>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return MBVAE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
     return mbvae_launch_status();
   }
-  if (g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  if (g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && getenv("MBVAE_TSGEMM_N64"))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
@@ -863,6 +881,7 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   if (A_KC) {
     const int st = tsgemm_try<B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
+    if (g.addend) return MBVAE_EUNSUPPORTED;       // the caller adds it with a separate pass
   } else if (!B_KC) {
     const int st = tswgrad_try(g, workspace, ws_bytes, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
@@ -953,6 +972,23 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
   g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
   g.accumulate = accumulate;
   return gemm_dispatch<true, false>(g, workspace, ws_bytes, stream);
+}
+
+// dx[M,K] = pro(dy)[M,N] @ w[N,K] + addend[M,K] (addend laid out like dx).  Only shapes served by the persistent
+// tall-skinny kernel are supported (MBVAE_EUNSUPPORTED otherwise: add in a separate pass).
+int mbvae_linear_bwd_input_add(const float* dy, int64_t lddy, const float* w, const float* addend, float* dx, int64_t lddx,
+                               int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
+                               const uint8_t* mask, int mask_mode, int n_nodes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (!addend || (gate && lddy != N)) return MBVAE_EINVAL;
+  GemmArgs g = {};
+  g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = (int)K; g.K = (int)N;
+  g.lda = lddy; g.ldb = K; g.ldc = lddx;
+  g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.addend = addend;
+  return gemm_dispatch<true, false>(g, nullptr, 0, stream);
 }
 
 // dw[N,K] = pro(dy)[M,N]^T @ x[M,K];  db[N] = column sums of pro(dy)  (db may be null)

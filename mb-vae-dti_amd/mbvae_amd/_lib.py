@@ -17,6 +17,7 @@ _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 SIGNATURES = {
     "mbvae_linear_fwd": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P, _I, _I, _F, _U, _I, _P, _L, _P],
     "mbvae_linear_bwd_input": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
+    "mbvae_linear_bwd_input_add": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _P],
     "mbvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
     "mbvae_edge_attn_fwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 6 + [_L, _L, _L, _F, _P],
     "mbvae_edge_attn_bwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P],
@@ -68,7 +69,9 @@ def load():
 PROFILE = None
 
 
-def call(name, *args, tag=None):
+def call(name, *args, tag=None, allow_unsupported=False):
+    """Runs one entry point and raises on failure.  With allow_unsupported, an 'unsupported shape' status is not an
+    error: the function returns False and the caller takes its other HIP route (never a CPU one)."""
     fn = getattr(load(), name)
     if PROFILE is None:
         st = fn(*args)
@@ -78,9 +81,13 @@ def call(name, *args, tag=None):
         start.record()
         st = fn(*args)
         end.record()
-        PROFILE.setdefault((name, tag), []).append((start, end))
+        if st == 0:
+            PROFILE.setdefault((name, tag), []).append((start, end))
+    if st == -2 and allow_unsupported:
+        return False
     if st != 0:
         raise RuntimeError(f"{name} failed: {_STATUS.get(st, st)}")
+    return True
 
 
 def query(name, *args):

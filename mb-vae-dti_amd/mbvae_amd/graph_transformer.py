@@ -70,21 +70,25 @@ class NodeEdgeBlock(nn.Module):
         b = torch.cat([l.bias for l in layers], 0)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False):
+        """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
+        use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input)."""
         n = X.shape[1]
         dx = self.dx
         node = dict(mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
         edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
         QKV = self._fused(X, (self.q, self.k, self.v), **node)                   # [bs,n,3dx]
-        E12 = self._fused(E, (self.e_mul, self.e_add), **edge)                   # [bs,n,n,2dx]
+        w12 = torch.cat((self.e_mul.weight, self.e_add.weight), 0)
+        b12 = torch.cat((self.e_mul.bias, self.e_add.bias), 0)
+        E12, e_stats, E_alias = ops.edge_input(E, w12, b12, node_mask, n)        # [bs,n,n,2dx], [bs,4de], E
         yp = self._fused(y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         P, wV = ops.edge_attention(QKV, E12, ye_add, ye_mul, node_mask, self.n_head)
         newE = _lin(self.e_out, P, **edge)
         newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
-        new_y = yy + self.x_y(X) + self.e_y(E)
+        new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)
         new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
-        return newX, newE, new_y
+        return (newX, newE, new_y, E_alias) if return_edge_alias else (newX, newE, new_y)
 
 
 class XEyTransformerLayer(nn.Module):
@@ -107,7 +111,7 @@ class XEyTransformerLayer(nn.Module):
     def forward(self, X, E, y, node_mask, seeds=None):
         p = self.dropout_p if self.training else 0.0
         seeds = seeds or _SeedStream(p > 0)
-        newX, newE, new_y = self.self_attn(X, E, y, node_mask)
+        newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True)
 
         def norm(ln, x, r):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())

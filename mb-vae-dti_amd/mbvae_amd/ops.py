@@ -99,6 +99,81 @@ def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=
     return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed)
 
 
+# ------------------------------------------------------------------------------------------------ edge-tensor fan-out
+class _EdgeInput(torch.autograd.Function):
+    """The three consumers of a layer's edge tensor E in one autograd node: the fused e_mul|e_add projection, the
+    Etoy pooling statistics and the residual branch (an alias of E).  Their three gradients would otherwise meet in
+    two element-wise accumulation passes over [bs,n,n,de]; here the residual gradient rides in the projection's
+    input-gradient epilogue and the pooling gradient is accumulated by its own kernel."""
+
+    @staticmethod
+    def forward(ctx, E, w, b, mask, n_nodes):
+        E = _f32c(E, "E")
+        w = _f32c(w, "weight")
+        x2 = E.reshape(-1, E.shape[-1])
+        M, K = x2.shape
+        N = w.shape[0]
+        m8 = _mask_u8(mask)
+        ws = workspace(E.device)
+        y = torch.empty((M, N), dtype=torch.float32, device=E.device)
+        _lib.call("mbvae_linear_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N, 0,
+                  m8.data_ptr(), MASK_EDGE, n_nodes, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+        bs, D = E.shape[0], E.shape[-1]
+        L = E.numel() // (bs * D)
+        stats = torch.empty((bs, 4 * D), dtype=torch.float32, device=E.device)
+        arg = torch.empty((bs, 2, D), dtype=torch.int32, device=E.device)
+        _lib.call("mbvae_pool_stats_fwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, L, D, _stream())
+        ctx.save_for_backward(E, w, m8, stats, arg)
+        ctx.cfg = (n_nodes, b is not None)
+        return y.reshape(*E.shape[:-1], N), stats, E.view_as(E)
+
+    @staticmethod
+    def backward(ctx, dy, dstats, dres):
+        E, w, m8, stats, arg = ctx.saved_tensors
+        n_nodes, has_bias = ctx.cfg
+        x2 = E.reshape(-1, E.shape[-1])
+        M, K = x2.shape
+        N = w.shape[0]
+        bs, D = E.shape[0], E.shape[-1]
+        L = E.numel() // (bs * D)
+        ws = workspace(E.device)
+        st = _stream()
+        dE = dw = db = None
+        dy2 = _f32c(dy, "dy").reshape(M, N) if dy is not None else None
+        if ctx.needs_input_grad[0]:
+            dE = torch.empty_like(E)
+            have = False
+            if dy2 is not None:
+                if dres is not None:
+                    dres = _f32c(dres, "dres")
+                    have = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dE.data_ptr(),
+                                     K, M, K, N, 0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, st, tag=(M, K, N),
+                                     allow_unsupported=True)
+                if not have:
+                    _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dE.data_ptr(), K, M, K, N, 0, 1.0,
+                              m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+                    if dres is not None:
+                        dE += dres
+            elif dres is not None:
+                dE.copy_(dres)
+            else:
+                dE.zero_()
+            if dstats is not None:
+                _lib.call("mbvae_pool_stats_bwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), _f32c(dstats).data_ptr(),
+                          dE.data_ptr(), bs, L, D, 1, st)
+        if ctx.needs_input_grad[1] and dy2 is not None:
+            dw = torch.empty((N, K), dtype=torch.float32, device=E.device)
+            db = torch.empty((N,), dtype=torch.float32, device=E.device) if has_bias else None
+            _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
+                      0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+        return dE, dw, db, None, None
+
+
+def edge_input(E, weight, bias, node_mask, n_nodes):
+    """(edge-masked E @ weight^T + bias, pooling statistics of E [bs, 4*de], alias of E for the residual branch)."""
+    return _EdgeInput.apply(E, weight, bias, node_mask, n_nodes)
+
+
 # ------------------------------------------------------------------------------------------------ edge attention
 class _EdgeAttention(torch.autograd.Function):
     """QKV [bs,n,3dx] = q|k|v and E12 [bs,n,n,2dx] = e_mul|e_add projection outputs (column blocks, read in place)."""

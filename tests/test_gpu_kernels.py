@@ -641,3 +641,27 @@ def test_denoiser_full_size_properties():
         sub = net(X[:9], E0[:9], y[:9], mask[:9])
         assert_close(sub.X, out.X[:9], rtol=2e-5, what="sub-batch X"); assert_close(sub.E, out.E[:9], rtol=2e-5, what="sub-batch E")
         assert_close(sub.y, out.y[:9], rtol=2e-5, what="sub-batch y")
+
+
+@pytest.mark.parametrize("bs,n,de,N", [(16, 64, 64, 512), (3, 9, 16, 64)])
+def test_edge_input_fanout(ops, bs, n, de, N):
+    """One autograd node for the three consumers of E (fused projection, pooling statistics, residual alias): values
+    and the summed gradient equal the three separate paths (large case: residual gradient folded into the
+    input-gradient epilogue; small case: the separate-add route)."""
+    g = torch.Generator().manual_seed(bs + n)
+    mask = ragged_mask(bs, n, g)
+    E = torch.randn(bs, n, n, de, generator=g)
+    w = torch.randn(N, de, generator=g) / math.sqrt(de); b = torch.randn(N, generator=g) * 0.1
+    c1, c2, c3 = torch.randn(bs, n, n, N, generator=g), torch.randn(bs, 4 * de, generator=g), torch.randn(bs, n, n, de, generator=g)
+    Er, wr, br = (t.clone().requires_grad_(True) for t in (E, w, b))
+    em = (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1).float()
+    y = F.linear(Er, wr, br) * em
+    flat = Er.reshape(bs, -1, de)
+    stats = torch.cat((flat.mean(1), flat.min(1).values, flat.max(1).values, flat.std(1)), 1)
+    ((y * c1).sum() + (stats * c2).sum() + (Er * c3).sum()).backward()
+    Eg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (E, w, b))
+    yg, sg, alias = ops.edge_input(Eg, wg, bg, mask.cuda(), n)
+    ((yg * c1.cuda()).sum() + (sg * c2.cuda()).sum() + (alias * c3.cuda()).sum()).backward()
+    assert_close(yg, y, what="projection"); assert_close(sg, stats, what="pool stats"); assert torch.equal(alias, Eg)
+    assert_close(Eg.grad, Er.grad, rtol=2e-5, what="dE"); assert_close(wg.grad, wr.grad, rtol=2e-5, what="dw")
+    assert_close(bg.grad, br.grad, rtol=2e-5, what="db")
