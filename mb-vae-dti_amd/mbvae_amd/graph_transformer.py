@@ -118,12 +118,15 @@ class XEyTransformerLayer(nn.Module):
 
         X, E, y = norm(self.normX1, X, newX), norm(self.normE1, E, newE), norm(self.norm_y1, y, new_y)
 
-        def ff(l1, l2, x):
-            return _lin(l2, _lin(l1, x, act=1, drop_p=p, seed=seeds.next()))
+        def ff_block(ln, l1, l2, x):
+            """norm(x + dropout(l2(dropout(relu(l1(x)))))); the residual branch uses l1's alias of x so that both
+            gradients of x meet inside l1's input-gradient product."""
+            h, x = _lin(l1, x, act=1, drop_p=p, seed=seeds.next(), with_alias=True)
+            return norm(ln, x, _lin(l2, h))
 
-        X = norm(self.normX2, X, ff(self.linX1, self.linX2, X))
-        E = norm(self.normE2, E, ff(self.linE1, self.linE2, E))
-        y = norm(self.norm_y2, y, ff(self.lin_y1, self.lin_y2, y))
+        X = ff_block(self.normX2, self.linX1, self.linX2, X)
+        E = ff_block(self.normE2, self.linE1, self.linE2, E)
+        y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y)
         return X, E, y
 
 

@@ -48,8 +48,11 @@ def _mask_u8(mask):
 
 # ------------------------------------------------------------------------------------------------ linear
 class _Linear(torch.autograd.Function):
+    """with_alias: also returns an alias of x for a second consumer (a residual branch); the alias' gradient is then
+    folded into the input-gradient product's epilogue instead of meeting it in a separate accumulation pass."""
+
     @staticmethod
-    def forward(ctx, x, w, b, act, mask, mask_mode, n_nodes, drop_p, seed):
+    def forward(ctx, x, w, b, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias):
         x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
         w = _f32c(w, "weight")
         M, K = x2.shape
@@ -63,10 +66,11 @@ class _Linear(torch.autograd.Function):
         gated = act == 1
         ctx.save_for_backward(x2, w, y if gated else None, m8)
         ctx.cfg = (mask_mode, n_nodes, float(drop_p), gated, b is not None, x.shape)
-        return y.reshape(*x.shape[:-1], N)
+        out = y.reshape(*x.shape[:-1], N)
+        return (out, x.view_as(x)) if with_alias else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x2, w, gate, m8 = ctx.saved_tensors
         mask_mode, n_nodes, drop_p, gated, has_bias, xshape = ctx.cfg
         M, K = x2.shape
@@ -79,24 +83,34 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, _ptr(gate),
-                      gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+            folded = False
+            if dres is not None:
+                dres = _f32c(dres, "dres").reshape(M, K)
+                folded = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dx.data_ptr(), K,
+                                   M, K, N, _ptr(gate), gscale, _ptr(m8), mm, n_nodes, _stream(), tag=(M, K, N),
+                                   allow_unsupported=True)
+            if not folded:
+                _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, _ptr(gate),
+                          gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+                if dres is not None:
+                    dx += dres
             dx = dx.reshape(xshape)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             db = torch.empty((N,), dtype=torch.float32, device=dy.device) if has_bias else None
             _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
                       _ptr(gate), gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=0, drop_p=0.0, seed=0):
-    """y = rowmask(dropout(act(x @ W^T + b))); act: 0 none, 1 ReLU.  Dropout is only supported after ReLU."""
+def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=0, drop_p=0.0, seed=0, with_alias=False):
+    """y = rowmask(dropout(act(x @ W^T + b))); act: 0 none, 1 ReLU.  Dropout is only supported after ReLU.
+    with_alias=True returns (y, alias of x): use the alias for x's other consumer (residual branch)."""
     if drop_p > 0 and act != 1:
         raise ValueError("dropout in the GEMM epilogue is only implemented after ReLU")
     if mask is None:
         mask_mode = MASK_NONE
-    return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed)
+    return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias)
 
 
 # ------------------------------------------------------------------------------------------------ edge-tensor fan-out
