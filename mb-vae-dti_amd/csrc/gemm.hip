@@ -803,6 +803,140 @@ __global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave-autonomous weight gradient: no LDS, no barrier.  Both operands of dW = pro(dY)^T X are row-contiguous, and the
+// MFMA A/B operand layouts want "lane = output column, lane half = reduction row", so a lane can read its operand
+// words straight from global memory: for the k-step over rows (r, r+1) lane (c, h) loads dY[r + h][p0 + 2c .. +1] and
+// X[r + h][q0 + 2c .. +1] (two 8-byte loads, each a pair of fully used 256-byte row segments per wave).  The two
+// words of a load feed two different 32x32 output tiles, i.e. a wave's 64x64 block of dW interleaves its two row
+// tiles (even / odd rows) and its two column tiles.  Eight waves cover WM x WN such blocks and share rows through
+// L1.  Loads run two 8-step groups (32 rows) ahead in a three-slot register ring; the wait for a group is pinned
+// right after the previous group's MFMAs, where the operand prologue (ReLU gate, row mask, scale) and the bias
+// gradient's column sums are applied in place.  Per-workgroup partials, fixed-order reduction as above.
+template <int P, int Q, int WM, int WN, bool GATE>
+__global__ __launch_bounds__(512) void tswgrad2_kernel(GemmArgs g, int nchunks) {
+  static_assert(WM * WN == 8 && P == 64 * WM && Q == 64 * WN, "8 waves, one 64x64 block each");
+  constexpr int KS = 8, GPC = 4;                   // k-steps per group, groups per 64-row chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+  const int my = (nchunks - bx + G - 1) / G;
+  const int total = my * GPC;
+  // addresses = wave-uniform row base (scalar registers) + a per-lane 32-bit offset fixed for the whole kernel
+  const unsigned offA = (unsigned)(h * g.lda + wm * 64 + 2 * r), offB = (unsigned)(h * g.ldb + wn * 64 + 2 * r);
+
+  float2 ra[3][KS], rb[3][KS], rg[3][KS];
+  unsigned ma[3], mb[3];
+  float cs0 = 0.f, cs1 = 0.f;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+#define W2_ROW0(q) ((int64_t)(bx + (min((q), total - 1) / GPC) * G) * 64)
+#define W2_FETCH(q, S)                                                                                \
+  {                                                                                                   \
+    const int qq = min((q), total - 1);                                                                \
+    const int64_t c0 = W2_ROW0(q);                                                                     \
+    const int64_t row = c0 + (qq % GPC) * 16;                                                          \
+    mbvae_row_mask_bytes(g.mask, g.a_mask_mode, c0 + lane, g.n_nodes, g.A, ma[S], mb[S]);              \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                   \
+      const float* arow = g.A + (row + 2 * s) * g.lda;                                                 \
+      const float* brow = g.B + (row + 2 * s) * g.ldb;                                                 \
+      ra[S][s] = *reinterpret_cast<const float2*>(arow + offA);                                        \
+      if (GATE) rg[S][s] = *reinterpret_cast<const float2*>(g.a_gate + (row + 2 * s) * g.lda + offA);  \
+      rb[S][s] = *reinterpret_cast<const float2*>(brow + offB);                                        \
+    }                                                                                                  \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+#define W2_PREP(q, S)                                                                                 \
+  {                                                                                                   \
+    unsigned late;                                                                                     \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late) : : "memory");                                         \
+    const unsigned long long kb = __ballot(mbvae_mask_keep(g.a_mask_mode, ma[S] | late, mb[S] | late)); \
+    const float sc = (q) < total ? g.a_gate_scale : 0.f;                                               \
+    if (!GATE && kb == ~0ull && sc == 1.f) {           /* nothing to apply: only pin the loads, sum columns */ \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                 \
+        float2 v = ra[S][s];                                                                           \
+        float2 b = rb[S][s];                                                                           \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
+        cs0 += v.x; cs1 += v.y;                                                                        \
+        ra[S][s] = v; rb[S][s] = b;                                                                    \
+      }                                                                                                \
+    } else {                                                                                           \
+      const unsigned kbits = (unsigned)(kb >> ((min((q), total - 1) % GPC) * 16 + h));  /* bit 2s: row 2s + h */ \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                 \
+        float2 v = ra[S][s];                                                                           \
+        float2 b = rb[S][s];                                                                           \
+        if (GATE) {                                                                                    \
+          if (!(rg[S][s].x > 0.f)) v.x = 0.f;                                                          \
+          if (!(rg[S][s].y > 0.f)) v.y = 0.f;                                                          \
+        }                                                                                              \
+        const float rk = ((kbits >> (2 * s)) & 1u) ? sc : 0.f;                                         \
+        v.x *= rk; v.y *= rk;                                                                          \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
+        cs0 += v.x; cs1 += v.y;                                                                        \
+        ra[S][s] = v; rb[S][s] = b;                                                                    \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define W2_MMA(S)                                                                                     \
+  {                                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                   \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[S][s].x, rb[S][s].x, acc[0][0], 0, 0, 0);    \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[S][s].x, rb[S][s].y, acc[0][1], 0, 0, 0);    \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[S][s].y, rb[S][s].x, acc[1][0], 0, 0, 0);    \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[S][s].y, rb[S][s].y, acc[1][1], 0, 0, 0);    \
+    }                                                                                                  \
+  }
+
+  if (total > 0) {
+    W2_FETCH(0, 0)
+    W2_FETCH(1, 1)
+    W2_PREP(0, 0)
+    for (int q = 0; q < total; q += 3) {
+      W2_FETCH(q + 2, 2)
+      W2_MMA(0)
+      W2_PREP(q + 1, 1)
+      W2_FETCH(q + 3, 0)
+      W2_MMA(1)                     /* groups past the end were scaled to zero */
+      W2_PREP(q + 2, 2)
+      W2_FETCH(q + 4, 1)
+      W2_MMA(2)
+      W2_PREP(q + 3, 0)
+    }
+  }
+#undef W2_ROW0
+#undef W2_FETCH
+#undef W2_PREP
+#undef W2_MMA
+
+  // ---- partial dW of this workgroup: tile (i, j) holds rows p = 64 wm + 2 m + i, columns 64 wn + 2 c + j
+  float* part = g.partial + (int64_t)bx * P * Q;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = (v & 3) + 8 * (v >> 2) + 4 * h;
+      const int row = wm * 64 + 2 * m + i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) part[row * Q + wn * 64 + 2 * r + j] = acc[i][j][v];
+    }
+  // ---- partial column sums of pro(dY): this lane summed the rows of its half; waves with wn == 0 own the columns
+  if (g.partial_colsum != nullptr) {
+    cs0 += __shfl_xor(cs0, 32, 64);
+    cs1 += __shfl_xor(cs1, 32, 64);
+    if (wn == 0 && h == 0) {
+      g.partial_colsum[(int64_t)bx * P + wm * 64 + 2 * r] = cs0;
+      g.partial_colsum[(int64_t)bx * P + wm * 64 + 2 * r + 1] = cs1;
+    }
+  }
+}
+
 // Sums `splits` partial [M,N] results (+ partial column sums) in a fixed order: 4 waves per 64 consecutive outputs,
 // wave z adds the partials z, z+4, ..., the four sums are combined through LDS.
 __global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int splits) {
@@ -840,6 +974,21 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
   if (!aligned || R < 32768 || R % 32 || P * Q > 32768 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
     return MBVAE_EUNSUPPORTED;
   if (P * Q > 16384 && !(P == 512 && Q == 64 && !g.a_gate)) return MBVAE_EUNSUPPORTED;
+  // the widest edge-path gradient (fused e_mul|e_add projection, 512 x 64) runs on the LDS-free kernel: 8 % faster there
+  if (!getenv("MBVAE_NO_TSWGRAD2") && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P == 512 && Q == 64 && !g.a_gate &&
+      (int64_t)2 * g.lda + P < 0x7fffffff) {
+    const int nchunks2 = R / 64;
+    const int grid2 = std::min(nchunks2, ts_num_cus());
+    const int64_t need2 = (int64_t)grid2 * ((int64_t)P * Q + P) * 4;
+    if (workspace != nullptr && ws_bytes >= need2) {
+      g.partial = (float*)workspace;
+      g.partial_colsum = g.colsum ? g.partial + (int64_t)grid2 * P * Q : nullptr;
+      hipLaunchKernelGGL((tswgrad2_kernel<512, 64, 8, 1, false>), dim3(grid2), dim3(512), 0, stream, g, nchunks2);
+      const int64_t total2 = (int64_t)P * Q + P;
+      hipLaunchKernelGGL(tswgrad_reduce_kernel, dim3((unsigned)((total2 + 63) / 64)), dim3(256), 0, stream, g, grid2);
+      return mbvae_launch_status();
+    }
+  }
   const int nchunks = R / 32;
   const int grid = std::min(nchunks, ts_num_cus());
   const int64_t need = (int64_t)grid * ((int64_t)P * Q + P) * 4;
