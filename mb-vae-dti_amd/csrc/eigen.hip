@@ -4,7 +4,8 @@
 // (rocSOLVER's generic batched path spends ~100 ms on 256 matrices of 64x64; this kernel needs ~1 ms).
 // Method: two-sided cyclic Jacobi with the round-robin ("circle") parallel ordering -- n/2 disjoint rotations
 // per round, n-1 rounds per sweep -- with the rotations of a round applied to rows, then to columns of A and
-// to the eigenvector matrix V by all 256 threads.  Rotations between decoupled index sets (a_pq == 0) are
+// to the eigenvector matrix V by all 1024 threads (the kernel is latency bound: one matrix per CU, so more waves per
+// matrix shorten every round).  Rotations between decoupled index sets (a_pq == 0) are
 // identities, so a block-diagonal Laplacian (disconnected graph) yields eigenvectors supported on single
 // components.  Eigenvalues come out ascending, eigenvectors in the columns of V, as LAPACK orders them.
 #include "common.h"
@@ -12,18 +13,19 @@
 #define EIG_MAX_N 64
 #define EIG_LD 65
 
-__global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __restrict__ A_in, float* __restrict__ W,
+#define EIG_NT 1024
+__global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __restrict__ A_in, float* __restrict__ W,
                                                              float* __restrict__ V_out, int n, int max_sweeps) {
   __shared__ float A[EIG_MAX_N * EIG_LD];
   __shared__ float V[EIG_MAX_N * EIG_LD];
   __shared__ float rot_c[EIG_MAX_N / 2], rot_s[EIG_MAX_N / 2];
   __shared__ int rot_p[EIG_MAX_N / 2], rot_q[EIG_MAX_N / 2];
-  __shared__ float red[4];
+  __shared__ float red[EIG_NT / 64];
   __shared__ float wsort[EIG_MAX_N];
   __shared__ int rank_of[EIG_MAX_N];
   const int tid = threadIdx.x;
   const float* src = A_in + (int64_t)blockIdx.x * n * n;
-  for (int e = tid; e < EIG_MAX_N * EIG_MAX_N; e += 256) {
+  for (int e = tid; e < EIG_MAX_N * EIG_MAX_N; e += EIG_NT) {
     const int i = e >> 6, j = e & 63;
     A[i * EIG_LD + j] = (i < n && j < n) ? src[i * n + j] : 0.f;
     V[i * EIG_LD + j] = (i == j) ? 1.f : 0.f;
@@ -31,11 +33,12 @@ __global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __rest
   __syncthreads();
   // scale for the convergence test: squared Frobenius norm
   float nrm = 0.f;
-  for (int e = tid; e < n * n; e += 256) { const float v = A[(e / n) * EIG_LD + (e % n)]; nrm += v * v; }
+  for (int e = tid; e < n * n; e += EIG_NT) { const float v = A[(e / n) * EIG_LD + (e % n)]; nrm += v * v; }
   nrm = wave_sum(nrm);
   if ((tid & 63) == 0) red[tid >> 6] = nrm;
   __syncthreads();
-  const float total2 = (red[0] + red[1]) + (red[2] + red[3]);
+  float total2 = 0.f;
+  for (int w = 0; w < EIG_NT / 64; ++w) total2 += red[w];
   __syncthreads();
 
   const int m = (n + 1) & ~1;            // even number of players (index n is a bye when n is odd)
@@ -43,14 +46,15 @@ __global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __rest
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     // off-diagonal mass
     float off = 0.f;
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += EIG_NT) {
       const int i = e / n, j = e % n;
       if (i != j) { const float v = A[i * EIG_LD + j]; off += v * v; }
     }
     off = wave_sum(off);
     if ((tid & 63) == 0) red[tid >> 6] = off;
     __syncthreads();
-    const float off2 = (red[0] + red[1]) + (red[2] + red[3]);
+    float off2 = 0.f;
+    for (int w = 0; w < EIG_NT / 64; ++w) off2 += red[w];
     __syncthreads();
     if (off2 <= 1e-14f * total2 || off2 == 0.f) break;
 
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __rest
       }
       __syncthreads();
       // rows: A <- J^T A
-      for (int e = tid; e < half * EIG_MAX_N; e += 256) {
+      for (int e = tid; e < half * EIG_MAX_N; e += EIG_NT) {
         const int pr = e >> 6, k = e & 63;
         const int p = rot_p[pr], q = rot_q[pr];
         const float c = rot_c[pr], s = rot_s[pr];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __rest
       }
       __syncthreads();
       // columns: A <- A J, V <- V J
-      for (int e = tid; e < half * EIG_MAX_N; e += 256) {
+      for (int e = tid; e < half * EIG_MAX_N; e += EIG_NT) {
         const int pr = e >> 6, k = e & 63;
         const int p = rot_p[pr], q = rot_q[pr];
         const float c = rot_c[pr], s = rot_s[pr];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void sym_eig_jacobi_kernel(const float* __rest
   }
   __syncthreads();
   float* dst = V_out + (int64_t)blockIdx.x * n * n;
-  for (int e = tid; e < n * n; e += 256) {
+  for (int e = tid; e < n * n; e += EIG_NT) {
     const int k = e / n, j = e % n;                      // V[k][j] -> column rank_of[j]
     dst[k * n + rank_of[j]] = V[k * EIG_LD + j];
   }
@@ -127,7 +131,7 @@ int mbvae_sym_eig(const float* A, float* W, float* V, int64_t bs, int64_t n, hip
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!A || !W || !V || bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (n > EIG_MAX_N || bs > 0x7fffffff) return MBVAE_EUNSUPPORTED;
-  hipLaunchKernelGGL(sym_eig_jacobi_kernel, dim3((unsigned)bs), dim3(256), 0, stream, A, W, V, (int)n, 16);
+  hipLaunchKernelGGL(sym_eig_jacobi_kernel, dim3((unsigned)bs), dim3(EIG_NT), 0, stream, A, W, V, (int)n, 16);
   return mbvae_launch_status();
 }
 
