@@ -52,8 +52,10 @@ class DenoiserTrainStep:
         self.graph_feats = ExtraFeatures(max_n_nodes=64)
         self.mol_feats = ExtraMolecularFeatures(VALENCIES, 1000.0, ATOM_WEIGHTS)
         self.sync = BucketedGradSync(self.model.parameters()) if distributed else None
+        # same update rule as the reference's AdamW(amsgrad=True); `fused` runs it as one multi-tensor kernel per
+        # dtype/device group instead of ~10 element-wise passes over the 73 M parameters
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=True,
-                                     foreach=True)
+                                     fused=True)
         self.last = {}
 
     def step(self, X0, E0, mask, cond):
