@@ -42,7 +42,8 @@ __global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
     float* __restrict__ P, float* __restrict__ wV, float* __restrict__ lse, int n, int dx, float scale,
     int ldq, int lde) {
   extern __shared__ __align__(16) float kv_rows[];          // STAGE: [2][n][256]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addressing on the scalar unit
   const int b = blockIdx.z, i = blockIdx.x * ROWS + wave;
   const int c = blockIdx.y * 256 + lane * 4;
   const int64_t node = (int64_t)b * n;
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
   // V rows of this block's 32 keys: re-read for every query row; from global memory they get evicted from L1/L2 by
   // the edge streams in between and come back from HBM (measured: +1 GB of fetches per launch)
   __shared__ __align__(16) float v_rows[32 * 256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addressing on the scalar unit
   const int b = blockIdx.z;
   const int c = blockIdx.x * 256 + lane * 4;
   const int cbase = blockIdx.x * 256;

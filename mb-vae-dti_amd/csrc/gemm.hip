@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   float* As = smem;
   float* Bs = smem + BK * LDAS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear block id so that
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
   float* As = Bs + g.K * LDB;                      // [2][BK][LDA]
   float* keepS = As + 2 * BK * LDA;                // [2][BM]  row-mask flags of the tile (epilogue)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int K = g.K;
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   const int N = g.N, LDB = N + 1;
   extern __shared__ __align__(16) float ts2_smem[];
   float* Bs = ts2_smem;                            // [K][LDB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int K = g.K;
   if (B_KC) {
@@ -488,6 +491,13 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  // On gfx950 the f32 MFMA shares the vector ALU's cycles (measured: every ordinary VALU instruction next to the MFMA
+  // stream costs ~3 of its 4 cycles of MFMA time), so the epilogue keeps its per-element VALU work minimal: the
+  // accumulators START at the bias, row-mask / ReLU code runs only when needed, and the stores are buffer stores
+  // whose row/column offset sits in a scalar register (no per-element address arithmetic).
+  const __amdgpu_buffer_rsrc_t rsrcC =
+      __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * 4), 0x00020000);
+  const int voffC = (int)((4u * h * ldc + r) * 4u);      // byte offset of (row 4h, column r) inside a task's tile
 
 #define TS2_TASK(qq, lt, gi, tile, cb)                                                                \
     const int lt = (qq) / gpt, gi = (qq) - lt * gpt;                                                   \
@@ -515,17 +525,29 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
     keepf[S] = mbvae_mask_keep(mask_mode, ma[S] | late, mb[S] | late) ? 1.f : 0.f;                     \
     float rk = g.a_mask_mode != MBVAE_MASK_NONE ? keepf[S] * g.a_gate_scale : g.a_gate_scale;          \
     if ((q) >= total) rk = 0.f;                                                                        \
-    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
-      float4 v = ra[S][p];                                                                             \
-      if (GATE) {                                                                                      \
-        if (!(rg[S][p].x > 0.f)) v.x = 0.f;                                                            \
-        if (!(rg[S][p].y > 0.f)) v.y = 0.f;                                                            \
-        if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                            \
-        if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                            \
+    if (!GATE && __ballot(rk != 1.f) == 0ull) {        /* nothing to apply in this wave: only pin the loads */ \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                  \
+        float4 v = ra[S][p];                                                                           \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                    \
+        ra[S][p] = v;                                                                                  \
       }                                                                                                \
-      v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                      \
-      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                      \
-      ra[S][p] = v;                                                                                    \
+    } else {                                                                                           \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                  \
+        float4 v = ra[S][p];                                                                           \
+        if (GATE) {                                                                                    \
+          if (!(rg[S][p].x > 0.f)) v.x = 0.f;                                                          \
+          if (!(rg[S][p].y > 0.f)) v.y = 0.f;                                                          \
+          if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                          \
+          if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                          \
+        }                                                                                              \
+        v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                    \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                    \
+        ra[S][p] = v;                                                                                  \
+      }                                                                                                \
+    }                                                                                                  \
+    if ((q) == 0) {                                    /* first task: accumulators start at its bias */ \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[j][v] = bjr[S][j] * has_bias;               \
     }                                                                                                  \
   }
 #define TS2_MMA(q, S)                                                                                 \
@@ -540,17 +562,22 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
       }                                                                                                \
     }                                                                                                  \
   }
-  // task finished: bias / ReLU / dropout / row mask, stores (32-bit element offsets: checked by the host)
+  // task finished: (bias is already in the accumulators) ReLU / dropout / row mask, stores; the accumulators restart
+  // at the NEXT task's bias, whose operands - bias included - sit in the other buffer and have been waited for
+#define TS2_ST(val, rr, j, sbase)                                                                     \
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrcC, voffC,                           \
+                                          (int)((sbase) + ((unsigned)(rr) * ldc + (j) * 32) * 4u), 0)
 #define TS2_EPI(q, S)                                                                                 \
   {                                                                                                   \
     TS2_TASK((q), lt, gi, tile, cb)                                                                    \
     if ((q) < total && gi == gpt - 1) {                                                                \
       const unsigned long long kb = g.c_mask_mode == MBVAE_MASK_NONE ? ~0ull : __ballot(keepf[S] != 0.f); \
       const unsigned kh = (unsigned)(kb >> (4 * h));   /* bit i: row 4h+i of the tile survives */      \
-      const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;                \
-      float bj[TN];                                                                                    \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) bj[j] = bjr[S][j] * has_bias;                     \
+      const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * 4u;   /* wave-uniform byte offset */ \
+      float bn[TN];                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = bjr[1 - S][j] * has_bias;                 \
       if (ADD) {                                       /* all addend loads first, then one wait */     \
+        const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;              \
         float ad[TN][16];                                                                              \
         _Pragma("unroll") for (int v = 0; v < 16; ++v)                                                 \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
@@ -559,37 +586,42 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
           _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
-            float o = acc[j][v] + bj[j];                                                               \
+            float o = acc[j][v];                                                                       \
             if (relu) o = fmaxf(o, 0.f);                                                               \
-            g.C[off0 + (unsigned)rr * ldc + j * 32] = (kr ? o : 0.f) + ad[j][v];                       \
-            acc[j][v] = 0.f;                                                                           \
+            TS2_ST((kr ? o : 0.f) + ad[j][v], rr, j, sbase);                                           \
           }                                                                                            \
         }                                                                                              \
+      } else if (!drop && !relu && kb == ~0ull) {      /* nothing but the stores */                    \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v)                                                 \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
+            TS2_ST(acc[j][v], (v & 3) + 8 * (v >> 2), j, sbase);                                       \
+          }                                                                                            \
       } else if (!drop) {                                                                              \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
           _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
-            float o = acc[j][v] + bj[j];                                                               \
+            float o = acc[j][v];                                                                       \
             if (relu) o = fmaxf(o, 0.f);                                                               \
-            g.C[off0 + (unsigned)rr * ldc + j * 32] = kr ? o : 0.f;                                    \
-            acc[j][v] = 0.f;                                                                           \
+            TS2_ST(kr ? o : 0.f, rr, j, sbase);                                                        \
           }                                                                                            \
         }                                                                                              \
       } else {                                                                                         \
+        const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;              \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
           _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
             const unsigned off = off0 + (unsigned)rr * ldc + j * 32;                                   \
-            float o = acc[j][v] + bj[j];                                                               \
+            float o = acc[j][v];                                                                       \
             if (relu) o = fmaxf(o, 0.f);                                                               \
             o *= mbvae_u01(g.seed, off) < g.drop_p ? 0.f : drop_keep;                                  \
-            g.C[off] = kr ? o : 0.f;                                                                   \
-            acc[j][v] = 0.f;                                                                           \
+            TS2_ST(kr ? o : 0.f, rr, j, sbase);                                                        \
           }                                                                                            \
         }                                                                                              \
       }                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[j][v] = bn[j];                              \
     }                                                                                                  \
   }
 
@@ -610,6 +642,7 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
 #undef TS2_PREP
 #undef TS2_MMA
 #undef TS2_EPI
+#undef TS2_ST
 }
 
 static int ts_num_cus() {
@@ -689,7 +722,8 @@ __global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
   float* As = tw_smem;                             // [2][BR][LDA]
   float* Bs = As + 2 * BR * LDA;                   // [2][BR][LDB]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int G = (int)gridDim.x, bx = (int)blockIdx.x;
@@ -817,7 +851,8 @@ template <int P, int Q, int WM, int WN, bool GATE>
 __global__ __launch_bounds__(512) void tswgrad2_kernel(GemmArgs g, int nchunks) {
   static_assert(WM * WN == 8 && P == 64 * WM && Q == 64 * WN, "8 waves, one 64x64 block each");
   constexpr int KS = 8, GPC = 4;                   // k-steps per group, groups per 64-row chunk
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int G = (int)gridDim.x, bx = (int)blockIdx.x;
