@@ -21,6 +21,25 @@
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Streaming accesses (every edge element is touched exactly once per kernel): the non-temporal hint keeps them from
+// displacing the node rows (Q, K, V, lse, ...) that all waves of a graph re-read out of L1/L2.
+typedef float ea_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4s(const float* p) {
+#ifdef MBVAE_EA_NO_NT
+  return ld4(p);
+#else
+  const ea_v4f v = __builtin_nontemporal_load(reinterpret_cast<const ea_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+#ifdef MBVAE_EA_NO_NT
+  st4(p, v);
+#else
+  ea_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<ea_v4f*>(p));
+#endif
+}
 
 #define F4_OP(out, expr)                                   \
   {                                                        \
@@ -67,13 +86,13 @@ __global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
   const int64_t erow = ((node + i) * n) * (int64_t)lde + c;
 #pragma unroll 4
   for (int j = 0; j < n; ++j) {
-    const float4 e1 = ld4(E1 + erow + (int64_t)j * lde);
-    const float4 e2 = ld4(E2 + erow + (int64_t)j * lde);
+    const float4 e1 = ld4s(E1 + erow + (int64_t)j * lde);
+    const float4 e2 = ld4s(E2 + erow + (int64_t)j * lde);
     const float4 k = STAGE ? ld4(&kv_rows[j * 256 + lane * 4]) : ld4(K + (node + j) * ldq + c);
     const float4 v = STAGE ? ld4(&kv_rows[(n + j) * 256 + lane * 4]) : ld4(V + (node + j) * ldq + c);
     float4 y; F4_OP(y, f4get(qs, _q) * f4get(k, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
     float4 p; F4_OP(p, f4get(ya, _q) + f4get(ym, _q) * f4get(y, _q));
-    st4(P + rowbase + (int64_t)j * dx, p);
+    st4s(P + rowbase + (int64_t)j * dx, p);
     if (mask[node + j]) {
       float4 mn; F4_OP(mn, fmaxf(f4get(m, _q), f4get(y, _q)));
       float4 corr; F4_OP(corr, __expf(f4get(m, _q) - f4get(mn, _q)));
@@ -158,9 +177,9 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
           if (j < n) {
             const int64_t off = rowbase + (int64_t)j * dx;
             const int64_t eoff = erow + (int64_t)j * lde;
-            const float4 e1 = ld4(E1 + eoff);
-            const float4 e2 = ld4(E2 + eoff);
-            const float4 dp = ld4(dP + off);
+            const float4 e1 = ld4s(E1 + eoff);
+            const float4 e2 = ld4s(E2 + eoff);
+            const float4 dp = ld4s(dP + off);
             const float4 vj = ld4(&v_rows[(wave + 16 * jj) * 256 + lane * 4]);
             float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));
             float4 y; F4_OP(y, f4get(qk, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
@@ -168,8 +187,8 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
             float4 dy; F4_OP(dy, f4get(dp, _q) * f4get(ym, _q) +
                                    f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q)));
             float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));
-            st4(dE1 + eoff, t);
-            st4(dE2 + eoff, dy);
+            st4s(dE1 + eoff, t);
+            st4s(dE2 + eoff, dy);
             float4 g; F4_OP(g, f4get(dy, _q) * (f4get(e1, _q) + 1.f));
             F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));
             F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);
