@@ -20,6 +20,14 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Streaming operand load for kernels whose wave-wide access covers whole cache lines that nobody touches again
+// (the chunk copies of the weight-gradient kernel): the non-temporal hint keeps them from occupying L2.  NOT for
+// accesses where a lane walks along its own row (the line is re-touched by the lane's next load and must stay in L1).
+typedef float gemm_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+  const gemm_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gemm_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -564,9 +572,12 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   }
   // task finished: (bias is already in the accumulators) ReLU / dropout / row mask, stores; the accumulators restart
   // at the NEXT task's bias, whose operands - bias included - sit in the other buffer and have been waited for
+#ifndef TS2_AUX
+#define TS2_AUX 2   /* non-temporal: the output is not read again by this kernel and must not displace the A rows */
+#endif
 #define TS2_ST(val, rr, j, sbase)                                                                     \
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrcC, voffC,                           \
-                                          (int)((sbase) + ((unsigned)(rr) * ldc + (j) * 32) * 4u), 0)
+                                          (int)((sbase) + ((unsigned)(rr) * ldc + (j) * 32) * 4u), TS2_AUX)
 #define TS2_EPI(q, S)                                                                                 \
   {                                                                                                   \
     TS2_TASK((q), lt, gi, tile, cb)                                                                    \
@@ -754,12 +765,12 @@ __global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
     const int64_t m0 = (int64_t)(bx + cc * G) * BR;                                                    \
     _Pragma("unroll") for (int p = 0; p < NA; ++p) {                                                   \
       const int64_t row = m0 + arow + RGA * p;                                                         \
-      ra[S][p] = *reinterpret_cast<const float4*>(g.A + row * g.lda + ac4);                            \
-      if (GATE) rg[S][p] = *reinterpret_cast<const float4*>(g.a_gate + row * g.lda + ac4);             \
+      ra[S][p] = ld4_stream(g.A + row * g.lda + ac4);                            \
+      if (GATE) rg[S][p] = ld4_stream(g.a_gate + row * g.lda + ac4);             \
       mbvae_row_mask_bytes(g.mask, g.a_mask_mode, row, g.n_nodes, g.A, ma[S][p], mb[S][p]);             \
     }                                                                                                  \
     _Pragma("unroll") for (int p = 0; p < NB; ++p) {                                                   \
-      const float4 t = *reinterpret_cast<const float4*>(g.B + (m0 + brow + RGB * p) * g.ldb + bc4);    \
+      const float4 t = ld4_stream(g.B + (m0 + brow + RGB * p) * g.ldb + bc4);    \
       rb[S][4 * p] = t.x; rb[S][4 * p + 1] = t.y; rb[S][4 * p + 2] = t.z; rb[S][4 * p + 3] = t.w;      \
     }                                                                                                  \
   }
