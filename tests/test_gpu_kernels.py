@@ -509,6 +509,15 @@ def test_full_model_sampling_and_val_step_run():
         for atoms, bonds in grp:
             assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
             assert int(atoms.min()) >= 0 and int(atoms.max()) < 8 and int(bonds.max()) < 5
+    # rank-sharded driver without a process group = the chunked single-device loop: same draws as sample_batch
+    from mbvae_amd.sharded_sampling import sample_sharded
+    sizes = torch.tensor([9, 4, 6])
+    sharded = sample_sharded(model, emb.cpu(), num_nodes=sizes, num_samples_per_embedding=2, chunk=6, seed=11)
+    torch.manual_seed(11)
+    direct = model.sample_batch(emb, num_nodes=sizes, num_samples_per_embedding=2, return_graphs=True)
+    for s_grp, d_grp in zip(sharded, direct):
+        for (sa, sb_), (da, db) in zip(s_grp, d_grp):
+            assert torch.equal(sa, da) and torch.equal(sb_, db)
     mask = g["mask"].bool().cuda()
     batch = {"features": {k: v.cuda() for k, v in g["feat_d"].items()}, "representations": {"smiles": ["C"] * 4},
              "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}

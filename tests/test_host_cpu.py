@@ -118,3 +118,58 @@ def test_bucketed_grad_sync_gloo_world2(tmp_path):
         v = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         tot = v if tot is None else tot + v
     assert torch.allclose(got, tot / 2, rtol=1e-6, atol=1e-7)
+
+
+class _FakeSampler(torch.nn.Module):
+    """Stands in for FullDTIModel.sample_batch on the CPU: molecules are a deterministic function of the embedding
+    row, so the gathered result can be compared with a single-process run."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.hparams = type("H", (), {"dataset_infos": {"general": {"max_n_nodes": 9}}})()
+        self.calls = []
+
+    def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False, **kw):
+        assert return_graphs
+        self.calls.append(drug_embeddings.size(0))
+        out = []
+        for row in drug_embeddings:
+            tag = int(row[0].item())
+            grp = []
+            for s in range(num_samples_per_embedding):
+                k = 3 + (tag + s) % 7
+                atoms = (torch.arange(k) + tag + s) % 5
+                bonds = ((torch.arange(k)[:, None] + torch.arange(k)[None, :] + tag) % 5) * (1 - torch.eye(k, dtype=torch.long))
+                grp.append((atoms, bonds))
+            out.append(grp)
+        return out
+
+
+def _sampling_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mbvae_amd.sharded_sampling import sample_sharded
+    model = _FakeSampler()
+    emb = torch.arange(11, dtype=torch.float32).unsqueeze(1).repeat(1, 4)      # 11 embeddings: ranks hold 6 and 5
+    res = sample_sharded(model, emb, num_samples_per_embedding=3, chunk=6, seed=5, device="cpu")
+    assert model.calls == ([2, 2, 2] if rank == 0 else [2, 2, 1])               # chunk 6 = 2 embeddings x 3 samples
+    assert (res is None) == (rank != 0)
+    if rank == 0:
+        torch.save([[list(pair) for pair in grp] for grp in res], out)
+    dist.destroy_process_group()
+
+
+def test_sharded_sampling_gloo_world2(tmp_path):
+    from mbvae_amd.sharded_sampling import sample_sharded, shard_bounds
+    assert [shard_bounds(11, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 11)]
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_sampling_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    emb = torch.arange(11, dtype=torch.float32).unsqueeze(1).repeat(1, 4)
+    want = sample_sharded(_FakeSampler(), emb, num_samples_per_embedding=3, chunk=6, device="cpu")   # no process group
+    assert len(got) == len(want) == 11
+    for g_grp, w_grp in zip(got, want):
+        assert len(g_grp) == len(w_grp) == 3
+        for (ga, gb), (wa, wb) in zip(g_grp, w_grp):
+            assert torch.equal(ga, wa) and torch.equal(gb, wb)

@@ -1,6 +1,7 @@
 """Reverse-diffusion sampling throughput (conditional generation, one chunk): molecule-steps/s on one MI355X.
 
     python tools/bench_sampling.py [--chunk 512] [--steps 20] [--nmax 64]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_sampling.py ...   (one chunk per rank)
 
 One step = FullDTIModel.sample_p_zs_given_zt: extra features (cycle counts, LDS Jacobi eigensolver) -> 8-layer denoiser
 forward (eval) -> reverse-step posterior + categorical draw (HIP).  Molecule sizes ~ N(28, 7^2) clipped to [8, nmax],
@@ -22,7 +23,13 @@ ap.add_argument("--fixed-n", type=int, default=0, help="all molecules of this si
 ap.add_argument("--buckets", type=int, default=1, help="size-sorted sub-batches (sample_batch(size_buckets=...))")
 ap.add_argument("--graph", action="store_true", help="capture one reverse step in a HIP graph and replay it")
 a = ap.parse_args()
-dev = torch.device("cuda")
+# molecules are independent: every rank samples its own chunk (generator seeded seed + rank), no collective in the loop
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+torch.cuda.set_device(dev)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
 cx, emb = 8, 1024
 mx = [0.72, 0.12, 0.06, 0.04, 0.02, 0.02, 0.01, 0.01]
 me = [0.90, 0.05, 0.03, 0.01, 0.01]
@@ -40,7 +47,8 @@ model = FullDTIModel(phase="pretrain_drug", finetune_score=None, learning_rate=5
                      factor=4, n_layers=3, activation="relu", dropout=0.1, bias=True, encoder_type="transformer",
                      aggregator_type="attentive", diffusion_steps=500, sample_every_val=5, val_samples_per_embedding=2,
                      test_samples_per_embedding=2, graph_transformer_kwargs=gt, dataset_infos=infos).to(dev).eval()
-g = torch.Generator().manual_seed(0)
+g = torch.Generator().manual_seed(rank)
+torch.manual_seed(1000 + rank)
 bs = a.chunk
 if a.fixed_n:
     n_nodes = torch.full((bs,), a.fixed_n)
@@ -87,7 +95,13 @@ with torch.no_grad():
         torch.cuda.synchronize()
         total_ms += 1000 * (time.perf_counter() - t0) / a.steps
 ms = total_ms                     # one reverse step of the whole chunk (all buckets)
-print(json.dumps({"metric": "molecule-steps/sec (reverse diffusion, 8-layer denoiser, fp32)", "value": round(bs / (ms * 1e-3), 1),
-                  "ms_per_step": round(ms, 3), "chunk": bs, "size_buckets": len(parts), "hip_graph": bool(a.graph), "n_max": int(n_nodes.max()),
+if world > 1:
+    worst = torch.tensor([ms], device=dev)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)          # the job ends with the slowest rank
+    ms = float(worst)
+    dist.destroy_process_group()
+if rank == 0:
+    print(json.dumps({"metric": "molecule-steps/sec (reverse diffusion, 8-layer denoiser, fp32)", "value": round(world * bs / (ms * 1e-3), 1),
+                  "n_gpus": world, "ms_per_step": round(ms, 3), "chunk": bs, "size_buckets": len(parts), "hip_graph": bool(a.graph), "n_max": int(n_nodes.max()),
                   "mean_atoms": round(float(n_nodes.float().mean()), 1), "steps_timed": a.steps,
-                  "projected_500x10000_s": round(ms * 1e-3 * 500 * 10000 / bs, 1), "data": "synthetic, random-init weights"}))
+                  "projected_500x10000_s": round(ms * 1e-3 * 500 * 10000 / (bs * world), 1), "data": "synthetic, random-init weights"}))
