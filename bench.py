@@ -186,6 +186,11 @@ def main():
             r = rows.get(nm)
             if r and r["ms"] > 0:
                 roofline[nm[6:] + "_GBps"] = round(ea_bytes[nm] / (r["ms"] / r["calls"] * 1e-3) / 1e9, 1)
+        # whole-step figures: ~15.0 GFLOP and, with only layer inputs/outputs touching memory, ~61.5 MB per graph
+        per_gpu_rate = bs * args.steps / elapsed
+        roofline["whole_step_TFLOPs"] = round(per_gpu_rate * 15.0e9 / 1e12, 2)
+        roofline["whole_step_mfma_frac"] = round(per_gpu_rate * 15.0e9 / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        roofline["whole_step_hbm_floor_frac"] = round(per_gpu_rate * 61.5e6 / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": "graphs/sec (train step, n=64, whole node)", "value": round(world * bs * args.steps / elapsed, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
