@@ -70,6 +70,18 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx, float scale,
                         mbvae_stream_t stream);
 
+/* ---- e_mul|e_add projection + edge attention in one forward kernel --------------------------------------
+ * Replaces graph_transformer.py:206-249 together with the e_mul / e_add Linear layers of :196-204 that feed it:
+ * E1|E2 = mask(E @ W12^T + b12) is computed on the matrix cores inside the attention kernel instead of making a
+ * round trip through memory.  E [bs,n,n,de] dense; W12 [2dx,de] = e_mul.weight over e_add.weight, b12 [2dx] or
+ * NULL; the other arguments as for mbvae_edge_attn_fwd.  E12 [bs,n,n,2dx] receives the projection output when it
+ * is not NULL (the backward entry points read it); with NULL nothing of that size is written.
+ * MBVAE_EUNSUPPORTED unless de == 64, dx == 256 and n <= 64: callers then use the two separate entry points. */
+int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                         float* P, float* wV, float* lse, float* E12, int64_t bs, int64_t n, int64_t de, int64_t dx,
+                         float scale, mbvae_stream_t stream);
+
 /* ---- residual + dropout + LayerNorm ------------------------------------------------------------------
  * Replaces `norm(X + dropout(newX))` of graph_transformer.py:125-144 (and nn.LayerNorm elsewhere with r = NULL). */
 int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,

@@ -1,0 +1,254 @@
+// Fused forward of the edge path's attention core: the e_mul|e_add projection of E runs on the matrix cores INSIDE
+// the attention kernel, so the two [bs,n,n,dx] projection outputs never make a round trip through HBM.
+//
+//   E1|E2[b,i,j,:] = E[b,i,j,:] @ W12^T + b12            (zero where the pair (i,j) is masked)
+//   Y[b,i,j,c]     = Q[b,i,c] * K[b,j,c] / sqrt(df) * (E1[b,i,j,c] + 1) + E2[b,i,j,c]
+//   P[b,i,j,c]     = ye_add[b,c] + (ye_mul[b,c] + 1) * Y[b,i,j,c]
+//   wV[b,i,c]      = sum_j softmax_j(Y[b,i,:,c] over valid keys) * V[b,j,c],   lse = log-sum-exp of that softmax
+//
+// Fixed widths de = 64, dx = 256 and n <= 64 (the molecule-graph configuration); other shapes use the separate
+// projection and attention kernels.  One 512-thread workgroup per graph (or per block of query rows of a graph).
+// Wave w owns channels [32w, 32w+32) of E1 and of E2: its slice of W12 (64 x 64 floats) lives in 64 registers per
+// lane for the whole kernel, laid out as the MFMA B operand, so the products need no LDS at all; LDS holds the
+// graph's K and V rows.  A tile = 32 keys x 32 channels of one query row: the lane that owns (channel c, half h)
+// gets 16 keys of E1 and E2 in its accumulators, i.e. the softmax over keys runs down a lane's own registers and
+// meets the other half's 16 (or 48) keys in one cross-half exchange per query row.  The E rows (A operand) go from
+// global memory straight into MFMA operand registers, one tile ahead of the products.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct EdgeFusedArgs {
+  const float* E; const float* W; const float* bias;
+  const float* Q; const float* K; const float* V; int ldq;
+  const float* ye_add; const float* ye_mul; const uint8_t* mask;
+  float* P; float* wV; float* lse; float* E12;
+  int bs, n; float scale; int ichunks;
+};
+
+__device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <bool WRITE_E12>
+__global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
+  extern __shared__ __align__(16) float ef_kv[];   // K rows [64][256], then V rows [64][256]
+  float* Ks = ef_kv;
+  float* Vs = ef_kv + 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int c = wave * 32 + r;
+  const int n = a.n, ldq = a.ldq;
+  const int RT = (n + 31) >> 5;                    // key tiles per query row (1 or 2)
+
+  // B operands: step (p, e) of a tile multiplies reduction index 32h + 4p + e (the A registers hold 32 consecutive
+  // reduction indices of the lane's row), so the lane keeps W12[c][32h .. 32h+31] and W12[256 + c][32h .. 32h+31]
+  float w1[32], w2[32];
+  {
+    const float* p1 = a.W + (int64_t)c * 64 + 32 * h;
+    const float* p2 = a.W + (int64_t)(256 + c) * 64 + 32 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 t = ef_ld4(p1 + 4 * q), u = ef_ld4(p2 + 4 * q);
+      w1[4 * q] = t.x; w1[4 * q + 1] = t.y; w1[4 * q + 2] = t.z; w1[4 * q + 3] = t.w;
+      w2[4 * q] = u.x; w2[4 * q + 1] = u.y; w2[4 * q + 2] = u.z; w2[4 * q + 3] = u.w;
+    }
+  }
+  const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
+  const int ntasks = a.bs * a.ichunks;
+  const int ipc = (n + a.ichunks - 1) / a.ichunks;   // query rows per task
+
+  float4 ra[2][8];
+  float qv[2];
+  float m_run = -INFINITY, l_run = 0.f, av_run = 0.f;
+
+  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    const int b = task / a.ichunks, ic = task - b * a.ichunks;
+    const int i0 = ic * ipc, i1 = min(n, i0 + ipc);
+    const int64_t node = (int64_t)b * n;
+    __syncthreads();                               // every wave is done with the previous graph's K, V rows
+    for (int e = tid; e < n * 64; e += 512) {
+      const int j = e >> 6, c4 = (e & 63) * 4;
+      *reinterpret_cast<float4*>(Ks + j * 256 + c4) = ef_ld4(a.K + (node + j) * ldq + c4);
+      *reinterpret_cast<float4*>(Vs + j * 256 + c4) = ef_ld4(a.V + (node + j) * ldq + c4);
+    }
+    const unsigned long long kmask = __ballot(lane < n && a.mask[node + min(lane, n - 1)] != 0);   // bit j: key j valid
+    const float ya = a.ye_add[(int64_t)b * 256 + c], ym1 = a.ye_mul[(int64_t)b * 256 + c] + 1.f;
+    __syncthreads();
+    const int T = (i1 - i0) * RT;                  // tiles of this task
+    if (T <= 0) continue;
+
+    // tile t -> (query row, key tile); past the end the last tile is fetched again and never used
+#define EF_FETCH(t, S)                                                                                \
+    {                                                                                                 \
+      const int tt = min((t), T - 1);                                                                  \
+      const int ii = RT == 2 ? tt >> 1 : tt, mt = RT == 2 ? tt & 1 : 0;                                \
+      const int64_t qrow = node + i0 + ii;                                                             \
+      const int j = min(32 * mt + r, n - 1);                                                           \
+      const float* src = a.E + ((qrow * n + j) * 64 + 32 * h);                                         \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                    \
+      qv[S] = a.Q[qrow * ldq + c];                                                                     \
+      asm volatile("" : : : "memory");       /* issue the loads here, do not sink them to their use */ \
+    }
+#define EF_ST(ptr_rsrc, val, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ptr_rsrc, voff, soff, 2)
+#define EF_TILE(t, S)                                                                                 \
+    if ((t) < T) {                                                                                    \
+      const int ii = RT == 2 ? (t) >> 1 : (t), mt = RT == 2 ? (t) & 1 : 0;                             \
+      const int i = i0 + ii;                                                                           \
+      f32x16 acc1, acc2;                                                                               \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                  \
+        float4 t4 = ra[S][p];                                                                          \
+        asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                \
+        const float avs[4] = {t4.x, t4.y, t4.z, t4.w};                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w1[4 * p + e], acc1, 0, 0, 0);           \
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w2[4 * p + e], acc2, 0, 0, 0);           \
+        }                                                                                              \
+      }                                                                                                \
+      const bool qi_ok = (kmask >> i) & 1ull;                                                          \
+      const unsigned km32 = (unsigned)(kmask >> (32 * mt));                                            \
+      const float qs = qv[S] * a.scale;                                                                \
+      const float* Kp = Ks + (32 * mt + 4 * h) * 256 + c;                                              \
+      const float* Vp = Vs + (32 * mt + 4 * h) * 256 + c;                                              \
+      const int64_t prow = (node + i) * n;                                                             \
+      const __amdgpu_buffer_rsrc_t rsP =                                                               \
+          __builtin_amdgcn_make_buffer_rsrc(a.P + prow * 256, 0, n * 256 * 4, 0x00020000);             \
+      const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(                            \
+          WRITE_E12 ? a.E12 + prow * 512 : a.P, 0, WRITE_E12 ? n * 512 * 4 : 0, 0x00020000);           \
+      const int voffP = (4 * h * 256 + c) * 4, voffE = (4 * h * 512 + c) * 4;                          \
+      if (mt == 0) { m_run = -INFINITY; l_run = 0.f; av_run = 0.f; }                                   \
+      float y[16];                                                                                     \
+      if (qi_ok && km32 == 0xffffffffu) {          /* full tile, nothing masked */                     \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const float e1 = acc1[v], e2 = acc2[v];                                                      \
+          if (WRITE_E12) {                                                                             \
+            EF_ST(rsE, e1, voffE, (32 * mt + rr) * 2048);                                              \
+            EF_ST(rsE, e2, voffE, (32 * mt + rr) * 2048 + 1024);                                       \
+          }                                                                                            \
+          const float qk = qs * Kp[rr * 256];                                                          \
+          y[v] = qk * (e1 + 1.f) + e2;                                                                 \
+          EF_ST(rsP, ya + ym1 * y[v], voffP, (32 * mt + rr) * 1024);                                   \
+        }                                                                                              \
+        float tmax = y[0];                                                                             \
+        _Pragma("unroll") for (int v = 1; v < 16; ++v) tmax = fmaxf(tmax, y[v]);                       \
+        const float m_new = fmaxf(m_run, tmax);                                                        \
+        const float corr = __expf(m_run - m_new);                                                      \
+        l_run *= corr; av_run *= corr;                                                                 \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const float w = __expf(y[v] - m_new);                                                        \
+          l_run += w; av_run += w * Vp[rr * 256];                                                      \
+        }                                                                                              \
+        m_run = m_new;                                                                                 \
+      } else {                                                                                         \
+        const int rows_here = min(32, n - 32 * mt);                                                    \
+        const unsigned kml = km32 >> (4 * h);      /* bit rr: this lane's row rr is a valid key */     \
+        const unsigned inl = (rows_here >= 32 ? 0xffffffffu : ((1u << rows_here) - 1u)) >> (4 * h);    \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const bool key_ok = (kml >> rr) & 1u, in = (inl >> rr) & 1u;                                 \
+          const bool pair_ok = qi_ok && key_ok;                                                        \
+          const float e1 = pair_ok ? acc1[v] : 0.f, e2 = pair_ok ? acc2[v] : 0.f;                      \
+          const float kv = in ? Kp[rr * 256] : 0.f;                                                    \
+          const float yy = qs * kv * (e1 + 1.f) + e2;                                                  \
+          if (in) {                                                                                    \
+            if (WRITE_E12) {                                                                           \
+              EF_ST(rsE, e1, voffE, (32 * mt + rr) * 2048);                                            \
+              EF_ST(rsE, e2, voffE, (32 * mt + rr) * 2048 + 1024);                                     \
+            }                                                                                          \
+            EF_ST(rsP, ya + ym1 * yy, voffP, (32 * mt + rr) * 1024);                                   \
+          }                                                                                            \
+          y[v] = key_ok ? yy : -INFINITY;                                                              \
+        }                                                                                              \
+        float tmax = y[0];                                                                             \
+        _Pragma("unroll") for (int v = 1; v < 16; ++v) tmax = fmaxf(tmax, y[v]);                       \
+        const float m_new = fmaxf(m_run, tmax);                                                        \
+        if (m_new > -INFINITY) {                                                                       \
+          const float corr = __expf(m_run - m_new);                                                    \
+          l_run *= corr; av_run *= corr;                                                               \
+          _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                             \
+            const int rr = (v & 3) + 8 * (v >> 2);                                                     \
+            const bool key_ok = (kml >> rr) & 1u;                                                      \
+            const float w = key_ok ? __expf(y[v] - m_new) : 0.f;                                       \
+            const float vv = key_ok ? Vp[rr * 256] : 0.f;                                              \
+            l_run += w; av_run += w * vv;                                                              \
+          }                                                                                            \
+          m_run = m_new;                                                                               \
+        }                                                                                              \
+      }                                                                                                \
+      if (mt == RT - 1) {                          /* query row finished: join the two halves' keys */ \
+        const float mo = __shfl_xor(m_run, 32), lo = __shfl_xor(l_run, 32), ao = __shfl_xor(av_run, 32); \
+        const float M = fmaxf(m_run, mo);                                                              \
+        float o = 0.f, s = INFINITY;                                                                   \
+        if (M > -INFINITY) {                                                                           \
+          const float ea = __expf(m_run - M), eb = __expf(mo - M);                                     \
+          const float lt = l_run * ea + lo * eb;                                                       \
+          o = (av_run * ea + ao * eb) / lt;                                                            \
+          s = M + __logf(lt);                                                                          \
+        }                                                                                              \
+        if (h == 0) { a.wV[(node + i) * 256 + c] = o; a.lse[(node + i) * 256 + c] = s; }               \
+      }                                                                                                \
+    }
+
+    EF_FETCH(0, 0)
+    for (int t = 0; t < T; t += 2) {
+      EF_FETCH(t + 1, 1)
+      EF_TILE(t, 0)
+      EF_FETCH(t + 2, 0)
+      EF_TILE(t + 1, 1)
+    }
+#undef EF_FETCH
+#undef EF_TILE
+#undef EF_ST
+  }
+}
+
+static int ef_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+extern "C" {
+
+// E [bs,n,n,de] dense, W12 [2dx,de] (rows 0..dx-1: e_mul, dx..2dx-1: e_add), b12 [2dx] or null; Q,K,V [bs,n,dx]
+// rows ldq floats apart; ye_add, ye_mul [bs,dx]; mask [bs,n].  Outputs P [bs,n,n,dx], wV, lse [bs,n,dx] dense, and,
+// when E12 is not null, the projection output E1|E2 [bs,n,n,2dx] (what the backward kernels read).
+// MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.
+int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                         float* P, float* wV, float* lse, float* E12, int64_t bs, int64_t n, int64_t de, int64_t dx,
+                         float scale, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
+  if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
+  if (ldq < dx || (ldq & 3) || ldq > 0x7fffffff) return MBVAE_EINVAL;
+  const void* ptrs[] = {E, W12, Q, K, V, ye_add, ye_mul, P, wV, lse};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  if (!mask || ((uintptr_t)E12 & 15) || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
+  if (getenv("MBVAE_NO_EDGE_FUSED")) return MBVAE_EUNSUPPORTED;
+  // tasks = graphs x blocks of query rows; pick the split that fills the last round of workgroups best
+  const int cus = ef_num_cus();
+  int ichunks = 1;
+  double best = 0.0;
+  for (int cand = 1; cand <= 8 && cand <= n; cand *= 2) {
+    const int64_t tasks = bs * cand;
+    const double eff = (double)tasks / (double)(((tasks + cus - 1) / cus) * cus);
+    if (eff > best + 0.02) { best = eff; ichunks = cand; }
+  }
+  EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks};
+  const size_t smem = sizeof(float) * 2 * 64 * 256;
+  auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;
+  const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);
+  return mbvae_launch_status();
+}
+
+}  // extern "C"

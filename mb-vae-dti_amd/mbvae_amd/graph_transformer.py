@@ -80,10 +80,10 @@ class NodeEdgeBlock(nn.Module):
         QKV = self._fused(X, (self.q, self.k, self.v), **node)                   # [bs,n,3dx]
         w12 = torch.cat((self.e_mul.weight, self.e_add.weight), 0)
         b12 = torch.cat((self.e_mul.bias, self.e_add.bias), 0)
-        E12, e_stats, E_alias = ops.edge_input(E, w12, b12, node_mask, n)        # [bs,n,n,2dx], [bs,4de], E
         yp = self._fused(y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
-        P, wV = ops.edge_attention(QKV, E12, ye_add, ye_mul, node_mask, self.n_head)
+        # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
+        P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head)
         newE = _lin(self.e_out, P, **edge)
         newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
         new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)

@@ -145,42 +145,50 @@ class _EdgeInput(torch.autograd.Function):
     def backward(ctx, dy, dstats, dres):
         E, w, m8, stats, arg = ctx.saved_tensors
         n_nodes, has_bias = ctx.cfg
-        x2 = E.reshape(-1, E.shape[-1])
-        M, K = x2.shape
-        N = w.shape[0]
-        bs, D = E.shape[0], E.shape[-1]
-        L = E.numel() // (bs * D)
-        ws = workspace(E.device)
-        st = _stream()
-        dE = dw = db = None
-        dy2 = _f32c(dy, "dy").reshape(M, N) if dy is not None else None
-        if ctx.needs_input_grad[0]:
-            dE = torch.empty_like(E)
-            have = False
-            if dy2 is not None:
-                if dres is not None:
-                    dres = _f32c(dres, "dres")
-                    have = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dE.data_ptr(),
-                                     K, M, K, N, 0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, st, tag=(M, K, N),
-                                     allow_unsupported=True)
-                if not have:
-                    _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dE.data_ptr(), K, M, K, N, 0, 1.0,
-                              m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
-                    if dres is not None:
-                        dE += dres
-            elif dres is not None:
-                dE.copy_(dres)
-            else:
-                dE.zero_()
-            if dstats is not None:
-                _lib.call("mbvae_pool_stats_bwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), _f32c(dstats).data_ptr(),
-                          dE.data_ptr(), bs, L, D, 1, st)
-        if ctx.needs_input_grad[1] and dy2 is not None:
-            dw = torch.empty((N, K), dtype=torch.float32, device=E.device)
-            db = torch.empty((N,), dtype=torch.float32, device=E.device) if has_bias else None
-            _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
-                      0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+        dE, dw, db = _edge_input_grads(E, w, m8, stats, arg, n_nodes, has_bias, dy, dstats, dres,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dE, dw, db, None, None
+
+
+def _edge_input_grads(E, w, m8, stats, arg, n_nodes, has_bias, dy, dstats, dres, need_dE, need_dw):
+    """Gradients of the projection (dy), the pooling statistics (dstats) and the residual alias (dres) w.r.t. E, and
+    of the projection w.r.t. its weight and bias."""
+    x2 = E.reshape(-1, E.shape[-1])
+    M, K = x2.shape
+    N = w.shape[0]
+    bs, D = E.shape[0], E.shape[-1]
+    L = E.numel() // (bs * D)
+    ws = workspace(E.device)
+    st = _stream()
+    dE = dw = db = None
+    dy2 = _f32c(dy, "dy").reshape(M, N) if dy is not None else None
+    if need_dE:
+        dE = torch.empty_like(E)
+        have = False
+        if dy2 is not None:
+            if dres is not None:
+                dres = _f32c(dres, "dres")
+                have = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dE.data_ptr(),
+                                 K, M, K, N, 0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, st, tag=(M, K, N),
+                                 allow_unsupported=True)
+            if not have:
+                _lib.call("mbvae_linear_bwd_input", dy2.data_ptr(), N, w.data_ptr(), dE.data_ptr(), K, M, K, N, 0, 1.0,
+                          m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+                if dres is not None:
+                    dE += dres
+        elif dres is not None:
+            dE.copy_(dres)
+        else:
+            dE.zero_()
+        if dstats is not None:
+            _lib.call("mbvae_pool_stats_bwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), _f32c(dstats).data_ptr(),
+                      dE.data_ptr(), bs, L, D, 1, st)
+    if need_dw and dy2 is not None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=E.device)
+        db = torch.empty((N,), dtype=torch.float32, device=E.device) if has_bias else None
+        _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
+                  0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+    return dE, dw, db
 
 
 def edge_input(E, weight, bias, node_mask, n_nodes):
@@ -214,18 +222,23 @@ class _EdgeAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dP, dwV, _dlse):
         QKV, E12, ye_mul, m8, wV, lse = ctx.saved_tensors
-        bs, n, dx = wV.shape
-        dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=wV.device)
-        dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
-        dE12 = torch.empty_like(E12)
-        dQKV = torch.empty_like(QKV)
-        dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
-        q, e, dq, de = QKV.data_ptr(), E12.data_ptr(), dQKV.data_ptr(), dE12.data_ptr()
-        _lib.call("mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
-                  ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
-                  de, de + 4 * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, ctx.scale,
-                  _stream())
+        dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, ctx.scale, dP, dwV)
         return dQKV, dE12, dya, dym, None, None
+
+
+def _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV):
+    bs, n, dx = wV.shape
+    dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=wV.device)
+    dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
+    dE12 = torch.empty_like(E12)
+    dQKV = torch.empty_like(QKV)
+    dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
+    q, e, dq, de = QKV.data_ptr(), E12.data_ptr(), dQKV.data_ptr(), dE12.data_ptr()
+    _lib.call("mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
+              ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
+              de, de + 4 * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, scale,
+              _stream())
+    return dQKV, dE12, dya, dym
 
 
 def edge_attention(QKV, E12, ye_add, ye_mul, node_mask, n_head):
@@ -234,6 +247,64 @@ def edge_attention(QKV, E12, ye_add, ye_mul, node_mask, n_head):
     QKV [bs,n,3dx] holds the q|k|v projections side by side, E12 [bs,n,n,2dx] the e_mul|e_add projections."""
     P, wV, _ = _EdgeAttention.apply(QKV, E12, ye_add, ye_mul, node_mask, n_head)
     return P, wV
+
+
+class _EdgeBlock(torch.autograd.Function):
+    """_EdgeInput and _EdgeAttention as ONE node whose forward runs the e_mul|e_add projection inside the attention
+    kernel (mbvae_edge_fused_fwd): without gradients the [bs,n,n,2dx] projection output is never written, with
+    gradients it is written once (for the backward kernels) but not read back by the forward.  Shapes the fused
+    kernel does not take run the two separate forward kernels; the backward is the same either way."""
+
+    @staticmethod
+    def forward(ctx, E, w, b, QKV, ye_add, ye_mul, mask, n_head):
+        E, w, QKV, ye_add, ye_mul = (_f32c(t) for t in (E, w, QKV, ye_add, ye_mul))
+        bs, n, dx3 = QKV.shape
+        dx, de = dx3 // 3, E.shape[-1]
+        M, N = bs * n * n, 2 * dx
+        scale = 1.0 / math.sqrt(dx // n_head)
+        m8 = _mask_u8(mask)
+        dev = E.device
+        need_grad = any(ctx.needs_input_grad[:6])
+        P = torch.empty((bs, n, n, dx), dtype=torch.float32, device=dev)
+        wV = torch.empty((bs, n, dx), dtype=torch.float32, device=dev)
+        lse = torch.empty_like(wV)
+        E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev) if need_grad else None
+        q = QKV.data_ptr()
+        fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
+                          ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
+                          _ptr(E12), bs, n, de, dx, scale, _stream(), allow_unsupported=True)
+        if not fused:
+            if E12 is None:
+                E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev)
+            ws = workspace(dev)
+            _lib.call("mbvae_linear_fwd", E.data_ptr(), de, w.data_ptr(), _ptr(b), E12.data_ptr(), N, M, de, N, 0,
+                      m8.data_ptr(), MASK_EDGE, n, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, de, N))
+            e = E12.data_ptr()
+            _lib.call("mbvae_edge_attn_fwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, N,
+                      ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
+                      bs, n, dx, scale, _stream())
+        stats = torch.empty((bs, 4 * de), dtype=torch.float32, device=dev)
+        arg = torch.empty((bs, 2, de), dtype=torch.int32, device=dev)
+        _lib.call("mbvae_pool_stats_fwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, n * n, de, _stream())
+        if need_grad:
+            ctx.save_for_backward(E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse)
+        ctx.cfg = (n, b is not None, scale)
+        return P, wV, stats, E.view_as(E)
+
+    @staticmethod
+    def backward(ctx, dP, dwV, dstats, dres):
+        E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse = ctx.saved_tensors
+        n, has_bias, scale = ctx.cfg
+        dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV)
+        dE, dw, db = _edge_input_grads(E, w, m8, stats, arg, n, has_bias, dE12, dstats, dres,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dE, dw, db, dQKV, dya, dym, None, None
+
+
+def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head):
+    """(P, wV, pooling statistics of E, alias of E): edge_input followed by edge_attention, with the projection
+    output kept out of memory whenever the fused forward kernel takes the shape."""
+    return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head)
 
 
 # ------------------------------------------------------------------------------------------------ residual + LayerNorm
