@@ -95,19 +95,21 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
     if ((t) < T) {                                                                                    \
       const int ii = RT == 2 ? (t) >> 1 : (t), mt = RT == 2 ? (t) & 1 : 0;                             \
       const int i = i0 + ii;                                                                           \
-      f32x16 acc1, acc2;                                                                               \
-      _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
-      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                  \
-        float4 t4 = ra[S][p];                                                                          \
-        asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                \
-        const float avs[4] = {t4.x, t4.y, t4.z, t4.w};                                                 \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w1[4 * p + e], acc1, 0, 0, 0);           \
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w2[4 * p + e], acc2, 0, 0, 0);           \
-        }                                                                                              \
-      }                                                                                                \
       const bool qi_ok = (kmask >> i) & 1ull;                                                          \
       const unsigned km32 = (unsigned)(kmask >> (32 * mt));                                            \
+      f32x16 acc1, acc2;                                                                               \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
+      if (qi_ok && km32 != 0u) {                   /* a tile without a valid (query, key) pair needs no products */ \
+        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                \
+          float4 t4 = ra[S][p];                                                                        \
+          asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");              \
+          const float avs[4] = {t4.x, t4.y, t4.z, t4.w};                                               \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w1[4 * p + e], acc1, 0, 0, 0);         \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[e], w2[4 * p + e], acc2, 0, 0, 0);         \
+          }                                                                                            \
+        }                                                                                              \
+      }                                                                                                \
       const float qs = qv[S] * a.scale;                                                                \
       const float* Kp = Ks + (32 * mt + 4 * h) * 256 + c;                                              \
       const float* Vp = Vs + (32 * mt + 4 * h) * 256 + c;                                              \
