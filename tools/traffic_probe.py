@@ -52,6 +52,19 @@ with torch.enable_grad():
     torch.autograd.backward((P, wV), (dP, dW))
     mark("setup")
     del P, E12, dP
+    # projection fused into the attention forward: inference form (E1|E2 never written) and training form
+    Ef = torch.randn(bs, n, n, de, device=dev)
+    w12 = torch.randn(2 * dx, de, device=dev) / de ** 0.5; b12 = torch.zeros(2 * dx, device=dev)
+    with torch.no_grad():
+        ops.edge_block(Ef, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)      # warm-up (code load)
+        torch.cuda.synchronize()
+        mark("mbvae_edge_fused_fwd:inference")
+        ops.edge_block(Ef, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)
+    Eg = Ef.clone().requires_grad_(True)
+    mark("mbvae_edge_fused_fwd")
+    Pf = ops.edge_block(Eg, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)
+    mark("setup")
+    del Pf, Ef, Eg
     x = torch.randn(bs, n, n, de, device=dev, requires_grad=True); r = torch.randn_like(x).requires_grad_(True)
     g, b = torch.ones(de, device=dev, requires_grad=True), torch.zeros(de, device=dev, requires_grad=True)
     dy = torch.randn_like(x); ds = torch.randn(bs, 4 * de, device=dev)
