@@ -695,7 +695,8 @@ def _edge_block_reference(E, w12, b12, QKV, ya, ym, mask, n_head):
     return P, wV, stats
 
 
-@pytest.mark.parametrize("bs,n,sizes", [(3, 64, None), (4, 37, (37, 20, 5, 33)), (2, 20, (20, 11)), (2, 64, (64, 31))])
+@pytest.mark.parametrize("bs,n,sizes", [(3, 64, None), (4, 37, (37, 20, 5, 33)), (2, 20, (20, 11)), (2, 64, (64, 31)),
+                                        (1, 2, None), (5, 33, (33, 1, 32, 2, 17)), (70, 8, None)])
 def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
     """Projection-inside-attention forward kernel (de = 64, dx = 256): values and all gradients against a plain torch
     restatement, and identical behaviour to the two separate forward kernels, on full, ragged and single-tile graphs."""
