@@ -82,6 +82,16 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
                          float* P, float* wV, float* lse, float* E12, int64_t bs, int64_t n, int64_t de, int64_t dx,
                          float scale, mbvae_stream_t stream);
 
+/* ---- edge feed-forward block, inference form ----------------------------------------------------------
+ * Replaces `normE2(E + linE2(relu(linE1(E))))` of XEyTransformerLayer.forward (graph_transformer.py:139-142) when
+ * no gradient is needed and dropout is off (sampling, validation): one pass over the rows, nothing but x is read
+ * and nothing but out is written.  x, out [M,d]; W1 [dff,d], b1 [dff], W2 [d,dff], b2 [d] (torch Linear layouts,
+ * biases may be NULL); gamma, beta [d].  MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M % 32 == 0: callers then
+ * use mbvae_linear_fwd twice and mbvae_ln_residual_fwd. */
+int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* gamma, const float* beta, float* out, int64_t M, int64_t d, int64_t dff, float eps,
+                       mbvae_stream_t stream);
+
 /* ---- residual + dropout + LayerNorm ------------------------------------------------------------------
  * Replaces `norm(X + dropout(newX))` of graph_transformer.py:125-144 (and nn.LayerNorm elsewhere with r = NULL). */
 int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,

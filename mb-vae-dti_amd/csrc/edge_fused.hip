@@ -212,6 +212,120 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Inference-only edge feed-forward block in one pass over the rows:
+//     out = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta          x, out [M, 64], hidden width 128
+// (training keeps the separate kernels: its backward needs the hidden activations and the pre-norm sum in memory).
+// Both products run TRANSPOSED on the matrix cores so that they chain through registers: H^T = W1 X^T puts the row
+// index m on the lanes and the 128 hidden units in the accumulator registers, which is exactly the B-operand layout
+// of Y^T = W2 H^T (step (t, v) multiplies hidden unit 32t + (v&3) + 8(v>>2) of the lower half-wave with that unit
+// + 4 of the upper one; the A operand W2 is read from LDS at the matching indices).  After the second product a
+// lane holds 32 of its row's 64 outputs and lane + 32 the others: residual add and LayerNorm are register
+// arithmetic plus one cross-half exchange per statistic.  Per row 256 B are read and 256 B written; the separate
+// kernels move 2.3 KB.
+struct EdgeFfnArgs {
+  const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
+  const float* gamma; const float* beta; float* out; int64_t M; float eps;
+};
+
+__global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
+  constexpr int L1 = 65, L2 = 129;                  // LDS row strides of W1 [128][64] and W2 [64][128]
+  extern __shared__ __align__(16) float ff_lds[];
+  float* W1s = ff_lds;                              // [128][L1]
+  float* W2s = W1s + 128 * L1;                      // [64][L2]
+  float* b1s = W2s + 64 * L2;                       // [128]
+  float* b2s = b1s + 128;                           // [64]
+  float* gs = b2s + 64;                             // [64]
+  float* bs_ = gs + 64;                             // [64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 128 * 64; e += 512) { W1s[(e >> 6) * L1 + (e & 63)] = a.W1[e]; W2s[(e >> 7) * L2 + (e & 127)] = a.W2[e]; }
+  if (tid < 128) b1s[tid] = a.b1 ? a.b1[tid] : 0.f;
+  if (tid < 64) { b2s[tid] = a.b2 ? a.b2[tid] : 0.f; gs[tid] = a.gamma[tid]; bs_[tid] = a.beta[tid]; }
+  __syncthreads();
+
+  const int64_t ntiles = a.M / 32;
+  const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
+  const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
+  if (mine <= 0) return;
+  float4 ra[2][8];
+#define FF_FETCH(q, S)                                                                                \
+  {                                                                                                   \
+    const int64_t tile = wid + min((int64_t)(q), mine - 1) * nw;                                       \
+    const float* src = a.x + (tile * 32 + r) * 64 + 32 * h;                                            \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+#define FF_TILE(q, S)                                                                                 \
+  if ((q) < mine) {                                                                                   \
+    const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
+    /* hidden layer, transposed: rows = hidden units (4 tiles of 32), columns = the tile's 32 rows */  \
+    f32x16 hh[4];                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) hh[t][v] = b1s[32 * t + 4 * h + (v & 3) + 8 * (v >> 2)]; \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
+      float4 t4 = ra[S][p];                                                                            \
+      asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
+      const float xs[4] = {t4.x, t4.y, t4.z, t4.w};                                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+        const float* wcol = W1s + r * L1 + 32 * h + 4 * p + e;      /* W1[unit r + 32t][k], k as in xs */ \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
+          hh[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * t * L1], xs[e], hh[t], 0, 0, 0);      \
+      }                                                                                                \
+    }                                                                                                  \
+    /* output layer: the (ReLU'd) hidden registers are the B operand */                                \
+    f32x16 yy[2];                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = b2s[32 * u + 4 * h + (v & 3) + 8 * (v >> 2)]; \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                                 \
+        const float hv = fmaxf(hh[t][v], 0.f);                                                         \
+        const float* wcol = W2s + r * L2 + 32 * t + 4 * h + (v & 3) + 8 * (v >> 2);                    \
+        yy[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[0], hv, yy[0], 0, 0, 0);                     \
+        yy[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * L2], hv, yy[1], 0, 0, 0);               \
+      }                                                                                                \
+    }                                                                                                  \
+    /* residual + LayerNorm: this lane has columns 32u + 8g + 4h + (0..3) of row `tile*32 + r` */      \
+    const float* xrow = a.x + (tile * 32 + r) * 64 + 4 * h;                                            \
+    float z[2][16];                                                                                    \
+    float sum = 0.f;                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
+        const float4 xr = ef_ld4(xrow + 32 * u + 8 * gq);                                              \
+        z[u][4 * gq + 0] = yy[u][4 * gq + 0] + xr.x; z[u][4 * gq + 1] = yy[u][4 * gq + 1] + xr.y;      \
+        z[u][4 * gq + 2] = yy[u][4 * gq + 2] + xr.z; z[u][4 * gq + 3] = yy[u][4 * gq + 3] + xr.w;      \
+        sum += (z[u][4 * gq] + z[u][4 * gq + 1]) + (z[u][4 * gq + 2] + z[u][4 * gq + 3]);              \
+      }                                                                                                \
+    sum += __shfl_xor(sum, 32);                                                                        \
+    const float mean = sum * (1.f / 64.f);                                                             \
+    float sq = 0.f;                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) { z[u][v] -= mean; sq += z[u][v] * z[u][v]; }     \
+    sq += __shfl_xor(sq, 32);                                                                          \
+    const float rstd = rsqrtf(sq * (1.f / 64.f) + a.eps);                                              \
+    float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
+        const float4 gm = *reinterpret_cast<const float4*>(gs + 32 * u + 8 * gq + 4 * h);              \
+        const float4 bt = *reinterpret_cast<const float4*>(bs_ + 32 * u + 8 * gq + 4 * h);             \
+        float4 o;                                                                                      \
+        o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;      \
+        o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;      \
+        *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                                        \
+      }                                                                                                \
+  }
+  FF_FETCH(0, 0)
+  for (int64_t q = 0; q < mine; q += 2) {
+    FF_FETCH(q + 1, 1)
+    FF_TILE(q, 0)
+    FF_FETCH(q + 2, 0)
+    FF_TILE(q + 1, 1)
+  }
+#undef FF_FETCH
+#undef FF_TILE
+}
+
 static int ef_num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -255,6 +369,26 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);
+  return mbvae_launch_status();
+}
+
+// out [M,64] = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta with x [M,64], W1 [128,64], W2 [64,128]
+// (torch Linear layouts), b1 / b2 may be NULL.  Forward only (no dropout): the inference form of the edge
+// feed-forward block.  MBVAE_EUNSUPPORTED unless d == 64, dff == 128 and M % 32 == 0.
+int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* gamma, const float* beta, float* out, int64_t M, int64_t d, int64_t dff, float eps,
+                       hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (M <= 0) return MBVAE_EINVAL;
+  if (d != 64 || dff != 128 || (M & 31) || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {x, W1, W2, gamma, beta, out};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps};
+  const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64);
+  if (hipFuncSetAttribute((const void*)edge_ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return MBVAE_ELAUNCH;
+  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 

@@ -125,7 +125,11 @@ class XEyTransformerLayer(nn.Module):
             return norm(ln, x, _lin(l2, h))
 
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
-        E = ff_block(self.normE2, self.linE1, self.linE2, E)
+        if p == 0.0 and not torch.is_grad_enabled():      # sampling / validation: the edge block in one pass
+            E = ops.ffn_ln_inference(E, self.linE1.weight, self.linE1.bias, self.linE2.weight, self.linE2.bias,
+                                     self.normE2.weight, self.normE2.bias, self.eps)
+        else:
+            E = ff_block(self.normE2, self.linE1, self.linE2, E)
         y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y)
         return X, E, y
 

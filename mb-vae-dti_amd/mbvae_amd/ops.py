@@ -348,6 +348,21 @@ def ln_residual(x, r, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
     return _LnResidual.apply(x, r, _f32c(gamma), _f32c(beta), eps, drop_p, seed)
 
 
+def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5):
+    """LayerNorm(x + linear(relu(linear(x, w1, b1)), w2, b2)) * gamma + beta without gradients or dropout.
+    One fused kernel where the widths allow (64 -> 128 -> 64, rows % 32 == 0), else the three separate kernels."""
+    x = _f32c(x, "x")
+    d, dff = x.shape[-1], w1.shape[0]
+    rows = x.numel() // d
+    with torch.no_grad():
+        out = torch.empty_like(x)
+        if _lib.call("mbvae_edge_ffn_fwd", x.data_ptr(), _f32c(w1).data_ptr(), _ptr(b1), _f32c(w2).data_ptr(), _ptr(b2),
+                     _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), rows, d, dff, float(eps), _stream(),
+                     allow_unsupported=True):
+            return out
+        return ln_residual(x, linear(linear(x, w1, b1, act=1), w2, b2), gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 class _PoolStats(torch.autograd.Function):
     @staticmethod

@@ -761,3 +761,22 @@ def test_grad_sync_rccl_world1_matches_plain_step():
             assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), runs
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows", [32, 4 * 37 * 37 // 32 * 32, 3 * 64 * 64])
+def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
+    """Inference-only fused edge feed-forward + LayerNorm (64 -> 128 -> 64): against plain torch and against the
+    three separate kernels."""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 64, generator=g) * 1.5
+    w1, b1 = torch.randn(128, 64, generator=g) / 8, torch.randn(128, generator=g) * 0.1
+    w2, b2 = torch.randn(64, 128, generator=g) / 11, torch.randn(64, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ref = F.layer_norm(x + F.linear(F.relu(F.linear(x, w1, b1)), w2, b2), (64,), gamma, beta, 1e-5)
+    dv = [t.cuda() for t in (x, w1, b1, w2, b2, gamma, beta)]
+    got = ops.ffn_ln_inference(*dv, 1e-5)
+    assert_close(got, ref, what="fused ffn + LN")
+    monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
+    sep = ops.ffn_ln_inference(*dv, 1e-5)
+    assert_close(sep, ref, what="separate kernels")
+    assert_close(got, sep, rtol=3e-6, what="fused vs separate")
