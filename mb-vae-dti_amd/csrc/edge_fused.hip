@@ -260,16 +260,21 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
 #define FF_TILE(q, S)                                                                                 \
   if ((q) < mine) {                                                                                   \
     const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
+    /* a zero the optimiser cannot see through, added to the LDS indices of the small per-column vectors: their   \
+       160 values are loop invariant and would otherwise be hoisted into registers, spilling the accumulators */ \
+    int oz;                                                                                            \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));                                                        \
+    const int h4 = 4 * h + oz;                                                                         \
     /* hidden layer, transposed: rows = hidden units (4 tiles of 32), columns = the tile's 32 rows */  \
     f32x16 hh[4];                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
-      _Pragma("unroll") for (int v = 0; v < 16; ++v) hh[t][v] = b1s[32 * t + 4 * h + (v & 3) + 8 * (v >> 2)]; \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) hh[t][v] = b1s[32 * t + h4 + (v & 3) + 8 * (v >> 2)]; \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
       float4 t4 = ra[S][p];                                                                            \
       asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
       const float xs[4] = {t4.x, t4.y, t4.z, t4.w};                                                    \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
-        const float* wcol = W1s + r * L1 + 32 * h + 4 * p + e;      /* W1[unit r + 32t][k], k as in xs */ \
+        const float* wcol = W1s + r * L1 + 32 * h + 4 * p + e + oz;      /* W1[unit r + 32t][k], k as in xs */ \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                  \
           hh[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * t * L1], xs[e], hh[t], 0, 0, 0);      \
       }                                                                                                \
@@ -277,11 +282,11 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     /* output layer: the (ReLU'd) hidden registers are the B operand */                                \
     f32x16 yy[2];                                                                                      \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
-      _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = b2s[32 * u + 4 * h + (v & 3) + 8 * (v >> 2)]; \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = b2s[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                                 \
         const float hv = fmaxf(hh[t][v], 0.f);                                                         \
-        const float* wcol = W2s + r * L2 + 32 * t + 4 * h + (v & 3) + 8 * (v >> 2);                    \
+        const float* wcol = W2s + r * L2 + 32 * t + h4 + (v & 3) + 8 * (v >> 2);                    \
         yy[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[0], hv, yy[0], 0, 0, 0);                     \
         yy[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * L2], hv, yy[1], 0, 0, 0);               \
       }                                                                                                \
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
-        const float4 gm = *reinterpret_cast<const float4*>(gs + 32 * u + 8 * gq + 4 * h);              \
-        const float4 bt = *reinterpret_cast<const float4*>(bs_ + 32 * u + 8 * gq + 4 * h);             \
+        const float4 gm = *reinterpret_cast<const float4*>(gs + 32 * u + 8 * gq + h4);              \
+        const float4 bt = *reinterpret_cast<const float4*>(bs_ + 32 * u + 8 * gq + h4);             \
         float4 o;                                                                                      \
         o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;      \
         o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;      \
