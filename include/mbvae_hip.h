@@ -92,6 +92,14 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
                        const float* gamma, const float* beta, float* out, int64_t M, int64_t d, int64_t dff, float eps,
                        mbvae_stream_t stream);
 
+/* Inference form of `normE1(E + e_out(newE))` (graph_transformer.py:251-252 followed by :133-134): out [M,de] =
+ * LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta, P [M,dx], W [de,dx] (torch Linear layout), b [de] or NULL,
+ * keep(row) = edge mask of row (b,i,j) from mask [bs,n] with M = bs*n*n (NULL: all rows kept).
+ * MBVAE_EUNSUPPORTED unless dx == 256, de == 64, M % 32 == 0: callers then use mbvae_linear_fwd + mbvae_ln_residual_fwd. */
+int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
+                          int64_t n, const float* gamma, const float* beta, float* out, int64_t M, int64_t dx,
+                          int64_t de, float eps, mbvae_stream_t stream);
+
 /* ---- residual + dropout + LayerNorm ------------------------------------------------------------------
  * Replaces `norm(X + dropout(newX))` of graph_transformer.py:125-144 (and nn.LayerNorm elsewhere with r = NULL). */
 int mbvae_ln_residual_fwd(const float* x, const float* r, const float* gamma, const float* beta, float* y,

@@ -331,6 +331,112 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
 #undef FF_TILE
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Inference-only `normE1(E + e_out(P))`: out = LayerNorm(E + mask_ij * (W P + b)) * gamma + beta with P [M,256],
+// E, out [M,64].  Same transposed product and in-register LayerNorm as the feed-forward kernel above (rows on the
+// lanes, the 64 outputs of a row in the registers of two lanes); the reduction runs over four 64-wide groups of P's
+// channels, each group's operands fetched one group ahead.  Saves the round trip of e_out's output and one read of
+// E per row.
+struct EdgeOutArgs {
+  const float* P; const float* W; const float* b; const float* E; const uint8_t* mask; int n;
+  const float* gamma; const float* beta; float* out; int64_t M; float eps;
+};
+
+__global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
+  constexpr int LW = 257;                           // LDS row stride of W [64][256]
+  extern __shared__ __align__(16) float eo_lds[];
+  float* Ws = eo_lds;                               // [64][LW]
+  float* bsv = Ws + 64 * LW;                        // [64]
+  float* gs = bsv + 64;
+  float* bt_ = gs + 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 64 * 256; e += 512) Ws[(e >> 8) * LW + (e & 255)] = a.W[e];
+  if (tid < 64) { bsv[tid] = a.b ? a.b[tid] : 0.f; gs[tid] = a.gamma[tid]; bt_[tid] = a.beta[tid]; }
+  __syncthreads();
+
+  const int64_t ntiles = a.M / 32;
+  const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
+  const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
+  if (mine <= 0) return;
+  const int64_t total = mine * 4;                   // 64-wide reduction groups of this wave
+  float4 ra[2][8];
+  f32x16 yy[2];
+#define EO_FETCH(q, S)                                                                                \
+  {                                                                                                   \
+    const int64_t qq = min((int64_t)(q), total - 1);                                                   \
+    const int64_t tile = wid + (qq >> 2) * nw;                                                         \
+    const float* src = a.P + (tile * 32 + r) * 256 + (qq & 3) * 64 + 32 * h;                           \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+#define EO_GROUP(q, S)                                                                                \
+  if ((q) < total) {                                                                                  \
+    const int gi = (int)((q) & 3);                                                                     \
+    const int64_t tile = wid + ((q) >> 2) * nw;                                                        \
+    int oz;          /* opaque zero: keeps the loop-invariant LDS values from being hoisted into registers */ \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));                                                        \
+    const int h4 = 4 * h + oz;                                                                         \
+    if (gi == 0) {                                                                                     \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = bsv[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
+    }                                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
+      float4 t4 = ra[S][p];                                                                            \
+      asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
+      const float xs[4] = {t4.x, t4.y, t4.z, t4.w};                                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+        const float* wcol = Ws + r * LW + gi * 64 + 32 * h + 4 * p + e + oz;                           \
+        yy[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[0], xs[e], yy[0], 0, 0, 0);                  \
+        yy[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * LW], xs[e], yy[1], 0, 0, 0);            \
+      }                                                                                                \
+    }                                                                                                  \
+    if (gi == 3) {                                   /* row finished: mask, residual, LayerNorm */     \
+      const int64_t row = tile * 32 + r;                                                               \
+      unsigned ma, mb;                                                                                 \
+      mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, row, a.n, a.P, ma, mb);  \
+      const float keep = mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb) ? 1.f : 0.f; \
+      const float* xrow = a.E + row * 64 + 4 * h;                                                      \
+      float z[2][16];                                                                                  \
+      float sum = 0.f;                                                                                 \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                             \
+          const float4 xr = ef_ld4(xrow + 32 * u + 8 * gq);                                            \
+          z[u][4 * gq + 0] = yy[u][4 * gq + 0] * keep + xr.x; z[u][4 * gq + 1] = yy[u][4 * gq + 1] * keep + xr.y; \
+          z[u][4 * gq + 2] = yy[u][4 * gq + 2] * keep + xr.z; z[u][4 * gq + 3] = yy[u][4 * gq + 3] * keep + xr.w; \
+          sum += (z[u][4 * gq] + z[u][4 * gq + 1]) + (z[u][4 * gq + 2] + z[u][4 * gq + 3]);            \
+        }                                                                                              \
+      sum += __shfl_xor(sum, 32);                                                                      \
+      const float mean = sum * (1.f / 64.f);                                                           \
+      float sq = 0.f;                                                                                  \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) { z[u][v] -= mean; sq += z[u][v] * z[u][v]; }   \
+      sq += __shfl_xor(sq, 32);                                                                        \
+      const float rstd = rsqrtf(sq * (1.f / 64.f) + a.eps);                                            \
+      float* orow = a.out + row * 64 + 4 * h;                                                          \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                             \
+          const float4 gm = *reinterpret_cast<const float4*>(gs + 32 * u + 8 * gq + h4);               \
+          const float4 bt = *reinterpret_cast<const float4*>(bt_ + 32 * u + 8 * gq + h4);              \
+          float4 o;                                                                                    \
+          o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;    \
+          o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;    \
+          *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                                      \
+        }                                                                                              \
+    }                                                                                                  \
+  }
+  EO_FETCH(0, 0)
+  for (int64_t q = 0; q < total; q += 2) {
+    EO_FETCH(q + 1, 1)
+    EO_GROUP(q, 0)
+    EO_FETCH(q + 2, 0)
+    EO_GROUP(q + 1, 1)
+  }
+#undef EO_FETCH
+#undef EO_GROUP
+}
+
 static int ef_num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -394,6 +500,26 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
     return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
   hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
+  return mbvae_launch_status();
+}
+
+// out [M,64] = LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta with P [M,256], W [64,256], E [M,64]; keep(row)
+// is the edge mask of row (b,i,j) (mask [bs,n] with M = bs*n*n; NULL: no masking).  Forward only, no dropout: the
+// inference form of e_out followed by normE1.  MBVAE_EUNSUPPORTED unless dx == 256, de == 64, M % 32 == 0.
+int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
+                          int64_t n, const float* gamma, const float* beta, float* out, int64_t M, int64_t dx,
+                          int64_t de, float eps, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (M <= 0 || (mask && n <= 0)) return MBVAE_EINVAL;
+  if (dx != 256 || de != 64 || (M & 31) || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {P, W, E, gamma, beta, out};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps};
+  const size_t smem = sizeof(float) * (64 * 257 + 3 * 64);
+  if (hipFuncSetAttribute((const void*)edge_out_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return MBVAE_ELAUNCH;
+  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  hipLaunchKernelGGL(edge_out_ln_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 

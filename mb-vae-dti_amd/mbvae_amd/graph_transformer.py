@@ -70,7 +70,7 @@ class NodeEdgeBlock(nn.Module):
         b = torch.cat([l.bias for l in layers], 0)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask, return_edge_alias=False):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
         use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input)."""
         n = X.shape[1]
@@ -84,7 +84,11 @@ class NodeEdgeBlock(nn.Module):
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head)
-        newE = _lin(self.e_out, P, **edge)
+        if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
+            ln, eps = edge_norm
+            newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps)
+        else:
+            newE = _lin(self.e_out, P, **edge)
         newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
         new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)
         new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
@@ -111,12 +115,15 @@ class XEyTransformerLayer(nn.Module):
     def forward(self, X, E, y, node_mask, seeds=None):
         p = self.dropout_p if self.training else 0.0
         seeds = seeds or _SeedStream(p > 0)
-        newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True)
+        inference = p == 0.0 and not torch.is_grad_enabled()      # sampling / validation
+        newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
+                                              edge_norm=(self.normE1, self.eps) if inference else None)
 
         def norm(ln, x, r):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
 
-        X, E, y = norm(self.normX1, X, newX), norm(self.normE1, E, newE), norm(self.norm_y1, y, new_y)
+        X, y = norm(self.normX1, X, newX), norm(self.norm_y1, y, new_y)
+        E = newE if inference else norm(self.normE1, E, newE)      # (inference: newE already is normE1(E + e_out(.)))
 
         def ff_block(ln, l1, l2, x):
             """norm(x + dropout(l2(dropout(relu(l1(x)))))); the residual branch uses l1's alias of x so that both
@@ -125,7 +132,7 @@ class XEyTransformerLayer(nn.Module):
             return norm(ln, x, _lin(l2, h))
 
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
-        if p == 0.0 and not torch.is_grad_enabled():      # sampling / validation: the edge block in one pass
+        if inference:                                     # the edge feed-forward block in one pass
             E = ops.ffn_ln_inference(E, self.linE1.weight, self.linE1.bias, self.linE2.weight, self.linE2.bias,
                                      self.normE2.weight, self.normE2.bias, self.eps)
         else:

@@ -363,6 +363,22 @@ def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5):
         return ln_residual(x, linear(linear(x, w1, b1, act=1), w2, b2), gamma, beta, eps)
 
 
+def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5):
+    """LayerNorm(E + edge_mask * linear(P, w, b)) * gamma + beta without gradients or dropout: one fused kernel
+    where the widths allow (256 -> 64, rows % 32 == 0), else the projection and the residual LayerNorm kernels."""
+    P, E = _f32c(P, "P"), _f32c(E, "E")
+    dx, de = P.shape[-1], E.shape[-1]
+    rows = E.numel() // de
+    with torch.no_grad():
+        out = torch.empty_like(E)
+        m8 = _mask_u8(node_mask)
+        if _lib.call("mbvae_edge_out_ln_fwd", P.data_ptr(), _f32c(w).data_ptr(), _ptr(b), E.data_ptr(), m8.data_ptr(),
+                     n_nodes, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), rows, dx, de, float(eps),
+                     _stream(), allow_unsupported=True):
+            return out
+        return ln_residual(E, linear(P, w, b, mask=node_mask, mask_mode=MASK_EDGE, n_nodes=n_nodes), gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 class _PoolStats(torch.autograd.Function):
     @staticmethod

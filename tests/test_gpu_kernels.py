@@ -780,3 +780,25 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
     sep = ops.ffn_ln_inference(*dv, 1e-5)
     assert_close(sep, ref, what="separate kernels")
     assert_close(got, sep, rtol=3e-6, what="fused vs separate")
+
+
+@pytest.mark.parametrize("bs,n,sizes", [(2, 64, None), (2, 32, (32, 9)), (8, 20, (20, 3, 11, 20, 1, 7, 19, 2))])
+def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
+    """Inference-only e_out + residual + LayerNorm (256 -> 64, edge-masked projection): against plain torch and the
+    separate kernels."""
+    g = torch.Generator().manual_seed(bs * n)
+    sz = torch.full((bs,), n) if sizes is None else torch.tensor(sizes)
+    mask = torch.arange(n)[None, :] < sz[:, None]
+    em = (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1).float()
+    P = torch.randn(bs, n, n, 256, generator=g)
+    E = torch.randn(bs, n, n, 64, generator=g) * 1.3
+    w, b = torch.randn(64, 256, generator=g) / 16, torch.randn(64, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ref = F.layer_norm(E + F.linear(P, w, b) * em, (64,), gamma, beta, 1e-5)
+    args = (P.cuda(), w.cuda(), b.cuda(), E.cuda(), mask.cuda(), n, gamma.cuda(), beta.cuda(), 1e-5)
+    got = ops.edge_out_ln_inference(*args)
+    assert_close(got, ref, what="fused e_out + LN")
+    monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
+    sep = ops.edge_out_ln_inference(*args)
+    assert_close(sep, ref, what="separate kernels")
+    assert_close(got, sep, rtol=3e-6, what="fused vs separate")
