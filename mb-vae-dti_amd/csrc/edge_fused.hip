@@ -74,14 +74,25 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
     const unsigned long long kmask = __ballot(lane < n && a.mask[node + min(lane, n - 1)] != 0);   // bit j: key j valid
     const float ya = a.ye_add[(int64_t)b * 256 + c], ym1 = a.ye_mul[(int64_t)b * 256 + c] + 1.f;
     __syncthreads();
-    const int T = (i1 - i0) * RT;                  // tiles of this task
+    // The training form writes P and E1|E2 for every pair.  The inference form only walks the tiles up to the last
+    // valid query row and the last valid key: nothing reads P of a masked pair, and a masked query row's wV / lse
+    // are the constants 0 / +inf.
+    int RTq = RT, iend = i1;
+    if (!WRITE_E12) {
+      const int top = kmask ? 64 - __builtin_clzll(kmask) : 0;   // 1 + index of the last valid node
+      RTq = top > 32 ? 2 : 1;
+      iend = min(i1, top);
+      for (int i = max(i0, top); i < i1; ++i)
+        if (h == 0) { a.wV[(node + i) * 256 + c] = 0.f; a.lse[(node + i) * 256 + c] = INFINITY; }
+    }
+    const int T = (iend - i0) * RTq;               // tiles of this task
     if (T <= 0) continue;
 
     // tile t -> (query row, key tile); past the end the last tile is fetched again and never used
 #define EF_FETCH(t, S)                                                                                \
     {                                                                                                 \
       const int tt = min((t), T - 1);                                                                  \
-      const int ii = RT == 2 ? tt >> 1 : tt, mt = RT == 2 ? tt & 1 : 0;                                \
+      const int ii = RTq == 2 ? tt >> 1 : tt, mt = RTq == 2 ? tt & 1 : 0;                              \
       const int64_t qrow = node + i0 + ii;                                                             \
       const int j = min(32 * mt + r, n - 1);                                                           \
       const float* src = a.E + ((qrow * n + j) * 64 + 32 * h);                                         \
@@ -93,10 +104,12 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ptr_rsrc, voff, soff, 2)
 #define EF_TILE(t, S)                                                                                 \
     if ((t) < T) {                                                                                    \
-      const int ii = RT == 2 ? (t) >> 1 : (t), mt = RT == 2 ? (t) & 1 : 0;                             \
+      const int ii = RTq == 2 ? (t) >> 1 : (t), mt = RTq == 2 ? (t) & 1 : 0;                           \
       const int i = i0 + ii;                                                                           \
       const bool qi_ok = (kmask >> i) & 1ull;                                                          \
       const unsigned km32 = (unsigned)(kmask >> (32 * mt));                                            \
+      if (mt == 0) { m_run = -INFINITY; l_run = 0.f; av_run = 0.f; }                                   \
+      if (WRITE_E12 || (qi_ok && km32 != 0u)) {    /* inference: a tile without a valid pair is skipped */ \
       f32x16 acc1, acc2;                                                                               \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
       if (qi_ok && km32 != 0u) {                   /* a tile without a valid (query, key) pair needs no products */ \
@@ -119,7 +132,6 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(                            \
           WRITE_E12 ? a.E12 + prow * 512 : a.P, 0, WRITE_E12 ? n * 512 * 4 : 0, 0x00020000);           \
       const int voffP = (4 * h * 256 + c) * 4, voffE = (4 * h * 512 + c) * 4;                          \
-      if (mt == 0) { m_run = -INFINITY; l_run = 0.f; av_run = 0.f; }                                   \
       float y[16];                                                                                     \
       if (qi_ok && km32 == 0xffffffffu) {          /* full tile, nothing masked */                     \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           const float e1 = pair_ok ? acc1[v] : 0.f, e2 = pair_ok ? acc2[v] : 0.f;                      \
           const float kv = in ? Kp[rr * 256] : 0.f;                                                    \
           const float yy = qs * kv * (e1 + 1.f) + e2;                                                  \
-          if (in) {                                                                                    \
+          if (in && (WRITE_E12 || pair_ok)) {      /* inference: P of a masked pair is never read */  \
             if (WRITE_E12) {                                                                           \
               EF_ST(rsE, e1, voffE, (32 * mt + rr) * 2048);                                            \
               EF_ST(rsE, e2, voffE, (32 * mt + rr) * 2048 + 1024);                                     \
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           m_run = m_new;                                                                               \
         }                                                                                              \
       }                                                                                                \
-      if (mt == RT - 1) {                          /* query row finished: join the two halves' keys */ \
+      }                                                                                                \
+      if (mt == RTq - 1) {                         /* query row finished: join the two halves' keys */ \
         const float mo = __shfl_xor(m_run, 32), lo = __shfl_xor(l_run, 32), ao = __shfl_xor(av_run, 32); \
         const float M = fmaxf(m_run, mo);                                                              \
         float o = 0.f, s = INFINITY;                                                                   \
@@ -225,7 +238,24 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
 // kernels move 2.3 KB.
 struct EdgeFfnArgs {
   const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
-  const float* gamma; const float* beta; float* out; int64_t M; float eps;
+  const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
+};
+
+// Validity of the 32-row tiles a wave owns (tile k of the wave = global tile wid + k*nw), 64 at a time: one byte
+// gather + ballot per window; k only ever grows.  A null map marks every tile valid.
+struct EfTileWindow {
+  unsigned long long bits = 0ull;
+  int64_t base = -64;
+  __device__ __forceinline__ bool ok(const uint8_t* map, int64_t k, int64_t wid, int64_t nw, int64_t mine, int lane) {
+    if (!map) return true;
+    if (k >= base + 64) {
+      base = k;
+      const int64_t kk = k + lane;
+      const uint8_t v = kk < mine ? map[wid + kk * nw] : (uint8_t)0;
+      bits = __ballot(v != 0);
+    }
+    return (bits >> (k - base)) & 1ull;
+  }
 };
 
 __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
@@ -237,6 +267,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   float* b2s = b1s + 128;                           // [64]
   float* gs = b2s + 64;                             // [64]
   float* bs_ = gs + 64;                             // [64]
+  float* cst = bs_ + 64;                            // [8][64]: per wave, the output row shared by all padding rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -250,15 +281,34 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
   if (mine <= 0) return;
   float4 ra[2][8];
+  // Tiles marked 0 in tile_ok hold padding rows, all with the same values (the caller's guarantee): the first one a
+  // wave meets is evaluated like any other tile and its output row kept in LDS; the later ones only store that row.
+  // mode: 0 = evaluate, 1 = evaluate and keep the row, 2 = store the kept row (its operand fetch is pointed at
+  // tile 0, which stays in cache, so that the fetch itself remains unconditional).
+  EfTileWindow win;
+  int mode[2] = {0, 0};
+  bool have_cst = false;
+  float* my_cst = cst + wave * 64;
 #define FF_FETCH(q, S)                                                                                \
   {                                                                                                   \
-    const int64_t tile = wid + min((int64_t)(q), mine - 1) * nw;                                       \
+    const int64_t k = min((int64_t)(q), mine - 1);                                                     \
+    int md = 0;                                                                                        \
+    if (!win.ok(a.tile_ok, k, wid, nw, mine, lane)) { md = have_cst ? 2 : 1; have_cst = true; }        \
+    mode[S] = md;                                                                                      \
+    const int64_t tile = md == 2 ? 0 : wid + k * nw;                                                   \
     const float* src = a.x + (tile * 32 + r) * 64 + 32 * h;                                            \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
 #define FF_TILE(q, S)                                                                                 \
-  if ((q) < mine) {                                                                                   \
+  if ((q) < mine && mode[S] == 2) {                                                                   \
+    const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
+    float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                 \
+        *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) =                                           \
+            *reinterpret_cast<const float4*>(my_cst + 32 * u + 8 * gq + 4 * h);                        \
+  } else if ((q) < mine) {                                                                            \
     const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
     /* a zero the optimiser cannot see through, added to the LDS indices of the small per-column vectors: their   \
        160 values are loop invariant and would otherwise be hoisted into registers, spilling the accumulators */ \
@@ -318,7 +368,9 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
         o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;      \
         o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;      \
         *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                                        \
+        if (mode[S] == 1 && r == 0) *reinterpret_cast<float4*>(my_cst + 32 * u + 8 * gq + 4 * h) = o;  \
       }                                                                                                \
+    if (mode[S] == 1) asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   /* the row is in LDS */  \
   }
   FF_FETCH(0, 0)
   for (int64_t q = 0; q < mine; q += 2) {
@@ -339,7 +391,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
 // E per row.
 struct EdgeOutArgs {
   const float* P; const float* W; const float* b; const float* E; const uint8_t* mask; int n;
-  const float* gamma; const float* beta; float* out; int64_t M; float eps;
+  const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
 };
 
 __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
@@ -363,10 +415,15 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
   const int64_t total = mine * 4;                   // 64-wide reduction groups of this wave
   float4 ra[2][8];
   f32x16 yy[2];
+  // A tile marked 0 in tile_ok has no valid pair: its P rows are not read (the operand fetch is pointed at tile 0,
+  // which stays in cache, so that the fetch itself remains unconditional) and the products are skipped.
+  EfTileWindow win;
+  bool live[2] = {true, true};
 #define EO_FETCH(q, S)                                                                                \
   {                                                                                                   \
     const int64_t qq = min((int64_t)(q), total - 1);                                                   \
-    const int64_t tile = wid + (qq >> 2) * nw;                                                         \
+    live[S] = win.ok(a.tile_ok, qq >> 2, wid, nw, mine, lane);                                         \
+    const int64_t tile = live[S] ? wid + (qq >> 2) * nw : 0;                                           \
     const float* src = a.P + (tile * 32 + r) * 256 + (qq & 3) * 64 + 32 * h;                           \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
@@ -382,6 +439,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = bsv[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
     }                                                                                                  \
+    if (live[S])                                                                                       \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
       float4 t4 = ra[S][p];                                                                            \
       asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
@@ -396,15 +454,16 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       const int64_t row = tile * 32 + r;                                                               \
       unsigned ma, mb;                                                                                 \
       mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, row, a.n, a.P, ma, mb);  \
-      const float keep = mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb) ? 1.f : 0.f; \
+      const bool keep = live[S] && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb);   \
       const float* xrow = a.E + row * 64 + 4 * h;                                                      \
       float z[2][16];                                                                                  \
       float sum = 0.f;                                                                                 \
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                             \
           const float4 xr = ef_ld4(xrow + 32 * u + 8 * gq);                                            \
-          z[u][4 * gq + 0] = yy[u][4 * gq + 0] * keep + xr.x; z[u][4 * gq + 1] = yy[u][4 * gq + 1] * keep + xr.y; \
-          z[u][4 * gq + 2] = yy[u][4 * gq + 2] * keep + xr.z; z[u][4 * gq + 3] = yy[u][4 * gq + 3] * keep + xr.w; \
+          /* a select, not a product: P of a masked pair may hold anything (the attention kernel skips it) */ \
+          z[u][4 * gq + 0] = (keep ? yy[u][4 * gq + 0] : 0.f) + xr.x; z[u][4 * gq + 1] = (keep ? yy[u][4 * gq + 1] : 0.f) + xr.y; \
+          z[u][4 * gq + 2] = (keep ? yy[u][4 * gq + 2] : 0.f) + xr.z; z[u][4 * gq + 3] = (keep ? yy[u][4 * gq + 3] : 0.f) + xr.w; \
           sum += (z[u][4 * gq] + z[u][4 * gq + 1]) + (z[u][4 * gq + 2] + z[u][4 * gq + 3]);            \
         }                                                                                              \
       sum += __shfl_xor(sum, 32);                                                                      \
@@ -487,15 +546,15 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
 // (torch Linear layouts), b1 / b2 may be NULL.  Forward only (no dropout): the inference form of the edge
 // feed-forward block.  MBVAE_EUNSUPPORTED unless d == 64, dff == 128 and M % 32 == 0.
 int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                       const float* gamma, const float* beta, float* out, int64_t M, int64_t d, int64_t dff, float eps,
-                       hipStream_t stream) {
+                       const float* gamma, const float* beta, float* out, const uint8_t* tile_ok, int64_t M, int64_t d,
+                       int64_t dff, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0) return MBVAE_EINVAL;
   if (d != 64 || dff != 128 || (M & 31) || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {x, W1, W2, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
-  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps};
-  const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64);
+  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok};
+  const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
   if (hipFuncSetAttribute((const void*)edge_ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
@@ -507,14 +566,14 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
 // is the edge mask of row (b,i,j) (mask [bs,n] with M = bs*n*n; NULL: no masking).  Forward only, no dropout: the
 // inference form of e_out followed by normE1.  MBVAE_EUNSUPPORTED unless dx == 256, de == 64, M % 32 == 0.
 int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
-                          int64_t n, const float* gamma, const float* beta, float* out, int64_t M, int64_t dx,
-                          int64_t de, float eps, hipStream_t stream) {
+                          int64_t n, const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
+                          int64_t M, int64_t dx, int64_t de, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0 || (mask && n <= 0)) return MBVAE_EINVAL;
   if (dx != 256 || de != 64 || (M & 31) || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {P, W, E, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
-  EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps};
+  EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok};
   const size_t smem = sizeof(float) * (64 * 257 + 3 * 64);
   if (hipFuncSetAttribute((const void*)edge_out_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;

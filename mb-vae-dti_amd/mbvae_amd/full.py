@@ -675,9 +675,11 @@ class FullDTIModel(_Base):
 
         size_buckets > 1 sorts the molecules by size and runs that many equal-count sub-batches, each padded only to
         its own largest molecule (the dense n x n edge tensors make the cost grow with n_max^2); every molecule is
-        still sampled independently from the same distribution, only the order of the random draws differs.  The
-        default (1) is the reference's single dense batch.  use_graph replays one captured reverse step as a HIP
-        graph (see _reverse_diffusion)."""
+        still sampled independently from the same distribution, only the order of the random draws differs.  Inside
+        a sub-batch the molecules are laid out largest first, back and forth over blocks of one molecule per compute
+        unit: the attention kernel hands graph g to workgroup g mod #CUs, and this order gives every workgroup a
+        similar amount of work.  The default (1) is the reference's single dense batch in the caller's order.
+        use_graph replays one captured reverse step as a HIP graph (see _reverse_diffusion)."""
         if self.phase in ("pretrain_target", "finetune"):
             return []
         dev = drug_embeddings.device
@@ -690,11 +692,14 @@ class FullDTIModel(_Base):
         if size_buckets <= 1 or bs < 2 * size_buckets:
             graphs = self._reverse_diffusion(drug_embeddings, n_nodes, use_graph)
         else:
-            order = torch.argsort(n_nodes, stable=True)
+            order = torch.argsort(n_nodes, descending=True, stable=True)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
             graphs = [None] * bs
             for part in torch.tensor_split(order, size_buckets):
                 if part.numel() == 0:
                     continue
+                blocks = list(torch.split(part, cus))
+                part = torch.cat([blk.flip(0) if k % 2 else blk for k, blk in enumerate(blocks)])
                 for i, gph in zip(part.tolist(), self._reverse_diffusion(drug_embeddings[part], n_nodes[part], use_graph)):
                     graphs[i] = gph
         mols = graphs if return_graphs else [self._graph_to_mol(a, b) for a, b in graphs]

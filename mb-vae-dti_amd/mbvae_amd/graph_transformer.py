@@ -70,7 +70,7 @@ class NodeEdgeBlock(nn.Module):
         b = torch.cat([l.bias for l in layers], 0)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
         use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input)."""
         n = X.shape[1]
@@ -86,8 +86,11 @@ class NodeEdgeBlock(nn.Module):
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head)
         if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
             ln, eps = edge_norm
-            newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps)
+            newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps,
+                                             tile_map=tile_map)
         else:
+            if not P.requires_grad and not torch.is_grad_enabled():
+                ops.zero_masked_pairs_(P, node_mask)      # the no-gradient attention forward skips padding pairs
             newE = _lin(self.e_out, P, **edge)
         newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
         new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)
@@ -112,12 +115,16 @@ class XEyTransformerLayer(nn.Module):
         self.dropout_p = dropout
         self.eps = layer_norm_eps
 
-    def forward(self, X, E, y, node_mask, seeds=None):
+    def forward(self, X, E, y, node_mask, seeds=None, tile_map=None):
+        """tile_map (ops.edge_tile_map(node_mask), inference only): lets the fused edge kernels skip padding tiles.  It
+        relies on every padding pair row of E holding the same values, which holds for E as GraphTransformer feeds
+        it (padding rows enter as zeros and only pass through row-wise operations)."""
         p = self.dropout_p if self.training else 0.0
         seeds = seeds or _SeedStream(p > 0)
         inference = p == 0.0 and not torch.is_grad_enabled()      # sampling / validation
         newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
-                                              edge_norm=(self.normE1, self.eps) if inference else None)
+                                              edge_norm=(self.normE1, self.eps) if inference else None,
+                                              tile_map=tile_map if inference else None)
 
         def norm(ln, x, r):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
@@ -134,7 +141,7 @@ class XEyTransformerLayer(nn.Module):
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
         if inference:                                     # the edge feed-forward block in one pass
             E = ops.ffn_ln_inference(E, self.linE1.weight, self.linE1.bias, self.linE2.weight, self.linE2.bias,
-                                     self.normE2.weight, self.normE2.bias, self.eps)
+                                     self.normE2.weight, self.normE2.bias, self.eps, tile_map=tile_map)
         else:
             E = ff_block(self.normE2, self.linE1, self.linE2, E)
         y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y)
@@ -175,8 +182,12 @@ class GraphTransformer(nn.Module):
         hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
         hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
         hy = mlp(self.mlp_in_y, y, True)
+        # ragged batch without gradients: padding tiles of the edge tensor are skipped by the fused inference kernels
+        tile_map = None
+        if not torch.is_grad_enabled() and not self.training:
+            tile_map = ops.edge_tile_map(node_mask)
         for layer in self.tf_layers:
-            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds)
+            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map)
         oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
         oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
         oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]

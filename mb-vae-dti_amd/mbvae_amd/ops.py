@@ -303,7 +303,8 @@ class _EdgeBlock(torch.autograd.Function):
 
 def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head):
     """(P, wV, pooling statistics of E, alias of E): edge_input followed by edge_attention, with the projection
-    output kept out of memory whenever the fused forward kernel takes the shape."""
+    output kept out of memory whenever the fused forward kernel takes the shape.  Without gradients P is only
+    written for valid pairs (see zero_masked_pairs_)."""
     return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head)
 
 
@@ -348,34 +349,62 @@ def ln_residual(x, r, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
     return _LnResidual.apply(x, r, _f32c(gamma), _f32c(beta), eps, drop_p, seed)
 
 
-def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5):
+def edge_tile_map(node_mask):
+    """uint8 [bs*n*n/32]: 1 where the tile of 32 consecutive pair rows (b,i,j) holds a valid pair, 0 where all of
+    them are padding; None when bs*n*n is not a multiple of 32.  Lets the inference kernels below skip padding tiles
+    of ragged batches (the mask is the same for every layer and every reverse-diffusion step)."""
+    bs, n = node_mask.shape
+    if (bs * n * n) % 32:
+        return None
+    m = node_mask.bool()
+    pair = m.unsqueeze(1) & m.unsqueeze(2)
+    return pair.reshape(-1, 32).any(1).to(torch.uint8)
+
+
+def zero_masked_pairs_(P, node_mask):
+    """In place: P[b,i,j,:] = 0 where node i or j is masked.  The no-gradient form of edge_block leaves those rows
+    unwritten; every consumer other than the fused e_out kernel (which skips them itself) calls this first."""
+    m = node_mask.bool()
+    return P.masked_fill_(~(m.unsqueeze(1) & m.unsqueeze(2)).unsqueeze(-1), 0.0)
+
+
+def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5, tile_map=None):
     """LayerNorm(x + linear(relu(linear(x, w1, b1)), w2, b2)) * gamma + beta without gradients or dropout.
-    One fused kernel where the widths allow (64 -> 128 -> 64, rows % 32 == 0), else the three separate kernels."""
+    One fused kernel where the widths allow (64 -> 128 -> 64, rows % 32 == 0), else the three separate kernels.
+    tile_map (edge_tile_map): tiles marked 0 must consist of padding rows that all hold the same values; one of them
+    is evaluated and copied to the rest (same bits as evaluating each)."""
     x = _f32c(x, "x")
     d, dff = x.shape[-1], w1.shape[0]
     rows = x.numel() // d
+    if tile_map is not None and tile_map.numel() * 32 != rows:
+        raise ValueError("tile_map does not match the number of rows")
     with torch.no_grad():
         out = torch.empty_like(x)
         if _lib.call("mbvae_edge_ffn_fwd", x.data_ptr(), _f32c(w1).data_ptr(), _ptr(b1), _f32c(w2).data_ptr(), _ptr(b2),
-                     _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), rows, d, dff, float(eps), _stream(),
-                     allow_unsupported=True):
+                     _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), _ptr(tile_map), rows, d, dff,
+                     float(eps), _stream(), allow_unsupported=True):
             return out
         return ln_residual(x, linear(linear(x, w1, b1, act=1), w2, b2), gamma, beta, eps)
 
 
-def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5):
+def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5, tile_map=None):
     """LayerNorm(E + edge_mask * linear(P, w, b)) * gamma + beta without gradients or dropout: one fused kernel
-    where the widths allow (256 -> 64, rows % 32 == 0), else the projection and the residual LayerNorm kernels."""
+    where the widths allow (256 -> 64, rows % 32 == 0), else the projection and the residual LayerNorm kernels.
+    P is only read on valid pairs (it may be uninitialised elsewhere); tile_map (edge_tile_map) lets whole padding
+    tiles go unfetched."""
     P, E = _f32c(P, "P"), _f32c(E, "E")
     dx, de = P.shape[-1], E.shape[-1]
     rows = E.numel() // de
+    if tile_map is not None and tile_map.numel() * 32 != rows:
+        raise ValueError("tile_map does not match the number of rows")
     with torch.no_grad():
         out = torch.empty_like(E)
         m8 = _mask_u8(node_mask)
         if _lib.call("mbvae_edge_out_ln_fwd", P.data_ptr(), _f32c(w).data_ptr(), _ptr(b), E.data_ptr(), m8.data_ptr(),
-                     n_nodes, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), rows, dx, de, float(eps),
-                     _stream(), allow_unsupported=True):
+                     n_nodes, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), _ptr(tile_map), rows, dx,
+                     de, float(eps), _stream(), allow_unsupported=True):
             return out
+        P = zero_masked_pairs_(P.view(-1, n_nodes, n_nodes, dx), node_mask).view_as(P)
         return ln_residual(E, linear(P, w, b, mask=node_mask, mask_mode=MASK_EDGE, n_nodes=n_nodes), gamma, beta, eps)
 
 

@@ -727,8 +727,9 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
     assert_close(P, Pr, what="P"); assert_close(wV * xm.cuda(), Wr * xm, what="wV"); assert_close(stats, Sr, what="stats")
     for got, t, name in zip(grads, ref_in, ("dE", "dw12", "db12", "dQKV", "dye_add", "dye_mul")):
         assert_close(got, t.grad, rtol=3e-5, what=name)
-    P0, wV0, _, _ = run(False)                       # inference: no projection output is written at all
-    assert torch.equal(P0, P) and torch.equal(wV0, wV)
+    P0, wV0, _, _ = run(False)        # inference: no projection output is written at all, P only on valid pairs
+    pm = (mask.unsqueeze(1) & mask.unsqueeze(2)).cuda()
+    assert torch.equal(P0[pm], P[pm]) and torch.equal(wV0 * xm.cuda(), wV * xm.cuda())
     monkeypatch.setenv("MBVAE_NO_EDGE_FUSED", "1")   # the two separate forward kernels
     P1, wV1, stats1, grads1 = run(True)
     assert_close(P1, P, rtol=2e-6, what="P fused vs separate"); assert_close(wV1 * xm.cuda(), wV * xm.cuda(), rtol=2e-6, what="wV fused vs separate")
@@ -776,6 +777,19 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
     dv = [t.cuda() for t in (x, w1, b1, w2, b2, gamma, beta)]
     got = ops.ffn_ln_inference(*dv, 1e-5)
     assert_close(got, ref, what="fused ffn + LN")
+    # padding tiles: every row of a tile marked 0 holds the same values; the result must not change by a bit
+    if rows >= 64:
+        tiles = rows // 32
+        tm = (torch.rand(tiles, generator=g) < 0.5).to(torch.uint8)
+        tm[0], tm[-1] = 1, 0
+        xp = x.clone().view(tiles, 32, 64)
+        xp[tm == 0] = x[5]
+        xp = xp.view(rows, 64).cuda()
+        full = ops.ffn_ln_inference(xp, *dv[1:], 1e-5)
+        skip = ops.ffn_ln_inference(xp, *dv[1:], 1e-5, tile_map=tm.cuda())
+        assert torch.equal(full, skip), "padding-tile shortcut changed the result"
+        skip0 = ops.ffn_ln_inference(xp[:64].contiguous().fill_(0.25), *dv[1:], 1e-5, tile_map=torch.zeros(2, dtype=torch.uint8).cuda())
+        assert torch.equal(skip0, ops.ffn_ln_inference(torch.full((64, 64), 0.25).cuda(), *dv[1:], 1e-5))
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
     sep = ops.ffn_ln_inference(*dv, 1e-5)
     assert_close(sep, ref, what="separate kernels")
@@ -798,7 +812,50 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
     args = (P.cuda(), w.cuda(), b.cuda(), E.cuda(), mask.cuda(), n, gamma.cuda(), beta.cuda(), 1e-5)
     got = ops.edge_out_ln_inference(*args)
     assert_close(got, ref, what="fused e_out + LN")
+    # P of masked pairs is never read: poison it, and let whole padding tiles go unfetched
+    Pn = P.clone()
+    Pn[~em.bool().expand_as(P)] = float("nan")
+    tm = ops.edge_tile_map(mask.cuda())
+    assert tm is not None and int(tm.sum()) == int(em.reshape(-1, 32).any(1).sum())
+    got2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:], tile_map=tm)
+    assert torch.equal(got2, got), "masked pairs of P leaked into the result"
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
     sep = ops.edge_out_ln_inference(*args)
+    sep2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:])
+    assert torch.equal(sep2, sep), "separate kernels: masked pairs of P leaked into the result"
     assert_close(sep, ref, what="separate kernels")
     assert_close(got, sep, rtol=3e-6, what="fused vs separate")
+
+
+def test_denoiser_inference_padding_shortcuts_are_exact():
+    """Ragged batch without gradients: the denoiser's outputs with the padding-tile shortcuts of the fused inference
+    kernels equal, bit for bit, the outputs with the map switched off, and match the gradient-mode forward (separate
+    training kernels, everything evaluated) to rounding."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd import ops as O
+    from mbvae_amd.graph_transformer import GraphTransformer
+    from mbvae_amd.trainstep import CFG3, synthetic_graphs
+    cfg = dict(CFG3); cfg["n_layers"] = 3
+    torch.manual_seed(3)
+    net = GraphTransformer(**cfg).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    bs, n = 12, 40
+    sizes = torch.tensor([40, 7, 33, 12, 1, 25, 40, 18, 9, 31, 2, 16])
+    X0, E0, mask = synthetic_graphs(bs, n, "cuda", g, sizes=sizes)
+    Xin = torch.cat((X0, torch.randn(bs, n, 8, generator=g).cuda() * mask.unsqueeze(-1)), 2)
+    yin = torch.randn(bs, 1037, generator=g).cuda()
+    E0 = E0 * (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1)
+    with torch.no_grad():
+        a = net(Xin, E0, yin, mask)
+        real = O.edge_tile_map
+        try:
+            O.edge_tile_map = lambda m: None
+            b = net(Xin, E0, yin, mask)
+        finally:
+            O.edge_tile_map = real
+    assert real(mask) is not None and int(real(mask).sum()) < real(mask).numel()
+    assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E) and torch.equal(a.y, b.y)
+    c = net(Xin, E0, yin, mask)                      # gradients enabled: training-form kernels
+    assert_close(a.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(a.E, c.E.detach(), rtol=2e-5, what="E")
+    assert_close(a.y, c.y.detach(), rtol=2e-5, what="y")

@@ -21,6 +21,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--nmax", type=int, default=64)
 ap.add_argument("--fixed-n", type=int, default=0, help="all molecules of this size (0: N(28,7) clipped)")
 ap.add_argument("--buckets", type=int, default=1, help="size-sorted sub-batches (sample_batch(size_buckets=...))")
+ap.add_argument("--sort", action="store_true", help="with one bucket: still lay the molecules out by size")
 ap.add_argument("--graph", action="store_true", help="capture one reverse step in a HIP graph and replay it")
 a = ap.parse_args()
 # molecules are independent: every rank samples its own chunk (generator seeded seed + rank), no collective in the loop
@@ -57,8 +58,15 @@ else:
 n_nodes = n_nodes.to(dev)
 z_all = torch.randn(bs, emb, generator=g).to(dev)
 T = model.T
-order = torch.argsort(n_nodes, stable=True)
-parts = [p for p in torch.tensor_split(order, max(a.buckets, 1)) if p.numel()]
+if a.buckets > 1 or a.sort:                 # the layout sample_batch(size_buckets=...) uses
+    order = torch.argsort(n_nodes, descending=True, stable=True)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    parts = []
+    for p in torch.tensor_split(order, max(a.buckets, 1)):
+        if p.numel():
+            parts.append(torch.cat([blk.flip(0) if k % 2 else blk for k, blk in enumerate(torch.split(p, cus))]))
+else:
+    parts = [torch.arange(bs, device=dev)]
 total_ms = 0.0
 with torch.no_grad():
     for part in parts:
