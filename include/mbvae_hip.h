@@ -88,9 +88,9 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
  * Replaces `normE2(E + linE2(relu(linE1(E))))` of XEyTransformerLayer.forward (graph_transformer.py:139-142) when
  * no gradient is needed and dropout is off (sampling, validation): one pass over the rows, nothing but x is read
  * and nothing but out is written.  x, out [M,d]; W1 [dff,d], b1 [dff], W2 [d,dff], b2 [d] (torch Linear layouts,
- * biases may be NULL); gamma, beta [d].  MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M % 32 == 0: callers then
+ * biases may be NULL); gamma, beta [d].  MBVAE_EUNSUPPORTED unless d == 64, dff == 128: callers then
  * use mbvae_linear_fwd twice and mbvae_ln_residual_fwd.
- * tile_ok (NULL, or M/32 bytes): a 0 marks a tile of 32 consecutive rows that are ALL padding (pairs with a masked
+ * tile_ok (NULL, or ceil(M/32) bytes): a 0 marks a tile of 32 consecutive rows that are ALL padding (pairs with a masked
  * node).  The caller guarantees that every row of every such tile holds the same values -- true inside the denoiser,
  * where padding pairs enter as zeros and only pass through row-wise operations -- so the kernel evaluates one of them
  * per wave and stores that result to the others without reading them.  The output is bit-identical to tile_ok = NULL. */
@@ -101,9 +101,9 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
 /* Inference form of `normE1(E + e_out(newE))` (graph_transformer.py:251-252 followed by :133-134): out [M,de] =
  * LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta, P [M,dx], W [de,dx] (torch Linear layout), b [de] or NULL,
  * keep(row) = edge mask of row (b,i,j) from mask [bs,n] with M = bs*n*n (NULL: all rows kept).
- * MBVAE_EUNSUPPORTED unless dx == 256, de == 64, M % 32 == 0: callers then use mbvae_linear_fwd + mbvae_ln_residual_fwd.
+ * MBVAE_EUNSUPPORTED unless dx == 256, de == 64: callers then use mbvae_linear_fwd + mbvae_ln_residual_fwd.
  * P is only read where keep(row) holds: rows of masked pairs may be uninitialised (mbvae_edge_fused_fwd without E12
- * does not write them).  tile_ok (NULL, or M/32 bytes): a 0 marks a tile of 32 consecutive rows without any kept
+ * does not write them).  tile_ok (NULL, or ceil(M/32) bytes): a 0 marks a tile of 32 consecutive rows without any kept
  * row; its P rows are not even fetched.  The output is bit-identical to tile_ok = NULL. */
 int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
                           int64_t n, const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   if (tid < 64) { b2s[tid] = a.b2 ? a.b2[tid] : 0.f; gs[tid] = a.gamma[tid]; bs_[tid] = a.beta[tid]; }
   __syncthreads();
 
-  const int64_t ntiles = a.M / 32;
+  const int64_t ntiles = (a.M + 31) / 32;          // the last tile may be partial: loads clamp, stores are guarded
   const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
   const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
   if (mine <= 0) return;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     if (!win.ok(a.tile_ok, k, wid, nw, mine, lane)) { md = have_cst ? 2 : 1; have_cst = true; }        \
     mode[S] = md;                                                                                      \
     const int64_t tile = md == 2 ? 0 : wid + k * nw;                                                   \
-    const float* src = a.x + (tile * 32 + r) * 64 + 32 * h;                                            \
+    const float* src = a.x + min(tile * 32 + r, a.M - 1) * 64 + 32 * h;                                \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   if ((q) < mine && mode[S] == 2) {                                                                   \
     const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
     float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
+    if (tile * 32 + r < a.M)                                                                           \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                 \
         *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) =                                           \
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
       }                                                                                                \
     }                                                                                                  \
     /* residual + LayerNorm: this lane has columns 32u + 8g + 4h + (0..3) of row `tile*32 + r` */      \
-    const float* xrow = a.x + (tile * 32 + r) * 64 + 4 * h;                                            \
+    const bool inb = tile * 32 + r < a.M;                                                              \
+    const float* xrow = a.x + min(tile * 32 + r, a.M - 1) * 64 + 4 * h;                                \
     float z[2][16];                                                                                    \
     float sum = 0.f;                                                                                   \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
         float4 o;                                                                                      \
         o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;      \
         o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;      \
-        *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                                        \
+        if (inb) *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                               \
         if (mode[S] == 1 && r == 0) *reinterpret_cast<float4*>(my_cst + 32 * u + 8 * gq + 4 * h) = o;  \
       }                                                                                                \
     if (mode[S] == 1) asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   /* the row is in LDS */  \
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
   if (tid < 64) { bsv[tid] = a.b ? a.b[tid] : 0.f; gs[tid] = a.gamma[tid]; bt_[tid] = a.beta[tid]; }
   __syncthreads();
 
-  const int64_t ntiles = a.M / 32;
+  const int64_t ntiles = (a.M + 31) / 32;          // the last tile may be partial: loads clamp, stores are guarded
   const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
   const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
   if (mine <= 0) return;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
     const int64_t qq = min((int64_t)(q), total - 1);                                                   \
     live[S] = win.ok(a.tile_ok, qq >> 2, wid, nw, mine, lane);                                         \
     const int64_t tile = live[S] ? wid + (qq >> 2) * nw : 0;                                           \
-    const float* src = a.P + (tile * 32 + r) * 256 + (qq & 3) * 64 + 32 * h;                           \
+    const float* src = a.P + min(tile * 32 + r, a.M - 1) * 256 + (qq & 3) * 64 + 32 * h;               \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
@@ -451,7 +453,8 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       }                                                                                                \
     }                                                                                                  \
     if (gi == 3) {                                   /* row finished: mask, residual, LayerNorm */     \
-      const int64_t row = tile * 32 + r;                                                               \
+      const bool inb = tile * 32 + r < a.M;                                                            \
+      const int64_t row = min(tile * 32 + r, a.M - 1);                                                 \
       unsigned ma, mb;                                                                                 \
       mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, row, a.n, a.P, ma, mb);  \
       const bool keep = live[S] && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb);   \
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
           float4 o;                                                                                    \
           o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;    \
           o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;    \
-          *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                                      \
+          if (inb) *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                             \
         }                                                                                              \
     }                                                                                                  \
   }
@@ -544,40 +547,40 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
 
 // out [M,64] = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta with x [M,64], W1 [128,64], W2 [64,128]
 // (torch Linear layouts), b1 / b2 may be NULL.  Forward only (no dropout): the inference form of the edge
-// feed-forward block.  MBVAE_EUNSUPPORTED unless d == 64, dff == 128 and M % 32 == 0.
+// feed-forward block.  MBVAE_EUNSUPPORTED unless d == 64 and dff == 128.
 int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
                        const float* gamma, const float* beta, float* out, const uint8_t* tile_ok, int64_t M, int64_t d,
                        int64_t dff, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0) return MBVAE_EINVAL;
-  if (d != 64 || dff != 128 || (M & 31) || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  if (d != 64 || dff != 128 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {x, W1, W2, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok};
   const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
   if (hipFuncSetAttribute((const void*)edge_ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;
-  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 7) / 8, ef_num_cus());
   hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 
 // out [M,64] = LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta with P [M,256], W [64,256], E [M,64]; keep(row)
 // is the edge mask of row (b,i,j) (mask [bs,n] with M = bs*n*n; NULL: no masking).  Forward only, no dropout: the
-// inference form of e_out followed by normE1.  MBVAE_EUNSUPPORTED unless dx == 256, de == 64, M % 32 == 0.
+// inference form of e_out followed by normE1.  MBVAE_EUNSUPPORTED unless dx == 256, de == 64.
 int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
                           int64_t n, const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
                           int64_t M, int64_t dx, int64_t de, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0 || (mask && n <= 0)) return MBVAE_EINVAL;
-  if (dx != 256 || de != 64 || (M & 31) || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  if (dx != 256 || de != 64 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {P, W, E, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok};
   const size_t smem = sizeof(float) * (64 * 257 + 3 * 64);
   if (hipFuncSetAttribute((const void*)edge_out_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;
-  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 7) / 8, ef_num_cus());
   hipLaunchKernelGGL(edge_out_ln_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }

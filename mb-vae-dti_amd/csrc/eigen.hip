@@ -41,13 +41,25 @@ __global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __r
   for (int w = 0; w < EIG_NT / 64; ++w) total2 += red[w];
   __syncthreads();
 
-  const int m = (n + 1) & ~1;            // even number of players (index n is a bye when n is odd)
+  // Trailing all-zero rows (padding nodes of a ragged batch, isolated last atoms) are decoupled from everything:
+  // their eigenpairs (a_ii, e_i) are already in place, so the tournament only runs over the leading ne indices.
+  __shared__ int ne_s;
+  if (tid == 0) ne_s = 0;
+  __syncthreads();
+  if (tid < n) {
+    bool nz = false;
+    for (int j = 0; j < n; ++j) nz |= (j != tid) && A[tid * EIG_LD + j] != 0.f;
+    if (nz) atomicMax(&ne_s, tid + 1);
+  }
+  __syncthreads();
+  const int ne = ne_s;
+  const int m = (ne + 1) & ~1;           // even number of players (index ne is a bye when ne is odd)
   const int half = m / 2;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     // off-diagonal mass
     float off = 0.f;
-    for (int e = tid; e < n * n; e += EIG_NT) {
-      const int i = e / n, j = e % n;
+    for (int e = tid; e < ne * ne; e += EIG_NT) {
+      const int i = e / ne, j = e % ne;
       if (i != j) { const float v = A[i * EIG_LD + j]; off += v * v; }
     }
     off = wave_sum(off);
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __r
         else { p = (r + tid) % (m - 1); q = (r - tid + (m - 1)) % (m - 1); }
         if (p > q) { const int t = p; p = q; q = t; }
         float c = 1.f, s = 0.f;
-        if (q < n) {
+        if (q < ne) {
           const float apq = A[p * EIG_LD + q];
           if (fabsf(apq) > 1e-30f) {
             const float tau = (A[q * EIG_LD + q] - A[p * EIG_LD + p]) / (2.f * apq);
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __r
         const int pr = e >> 6, k = e & 63;
         const int p = rot_p[pr], q = rot_q[pr];
         const float c = rot_c[pr], s = rot_s[pr];
-        if (q < n && s != 0.f && k < n) {
+        if (q < ne && s != 0.f && k < ne) {
           const float ap = A[p * EIG_LD + k], aq = A[q * EIG_LD + k];
           A[p * EIG_LD + k] = c * ap - s * aq;
           A[q * EIG_LD + k] = s * ap + c * aq;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __r
         const int pr = e >> 6, k = e & 63;
         const int p = rot_p[pr], q = rot_q[pr];
         const float c = rot_c[pr], s = rot_s[pr];
-        if (q < n && s != 0.f && k < n) {
+        if (q < ne && s != 0.f && k < ne) {
           const float ap = A[k * EIG_LD + p], aq = A[k * EIG_LD + q];
           A[k * EIG_LD + p] = c * ap - s * aq;
           A[k * EIG_LD + q] = s * ap + c * aq;

@@ -669,7 +669,7 @@ class FullDTIModel(_Base):
 
     @torch.no_grad()
     def sample_batch(self, drug_embeddings, num_nodes=None, num_samples_per_embedding=1, return_graphs=False, size_buckets=1,
-                     use_graph=False):
+                     use_graph=False, balance=False):
         """Reverse diffusion from the limit distribution for T steps.  Returns molecules grouped per embedding
         (RDKit Mol objects when RDKit is available, else (atom ids, bond ids) tensor pairs).
 
@@ -678,7 +678,8 @@ class FullDTIModel(_Base):
         still sampled independently from the same distribution, only the order of the random draws differs.  Inside
         a sub-batch the molecules are laid out largest first, back and forth over blocks of one molecule per compute
         unit: the attention kernel hands graph g to workgroup g mod #CUs, and this order gives every workgroup a
-        similar amount of work.  The default (1) is the reference's single dense batch in the caller's order.
+        similar amount of work.  The default (1) is the reference's single dense batch in the caller's order;
+        balance=True applies the size-ordered layout to that single batch too.
         use_graph replays one captured reverse step as a HIP graph (see _reverse_diffusion)."""
         if self.phase in ("pretrain_target", "finetune"):
             return []
@@ -689,13 +690,15 @@ class FullDTIModel(_Base):
             drug_embeddings = drug_embeddings.repeat_interleave(num_samples_per_embedding, dim=0)
             n_nodes = n_nodes.repeat_interleave(num_samples_per_embedding)
         bs = n0 * num_samples_per_embedding
-        if size_buckets <= 1 or bs < 2 * size_buckets:
+        if bs < 2 * size_buckets:
+            size_buckets = 1
+        if size_buckets <= 1 and not balance:
             graphs = self._reverse_diffusion(drug_embeddings, n_nodes, use_graph)
         else:
             order = torch.argsort(n_nodes, descending=True, stable=True)
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             graphs = [None] * bs
-            for part in torch.tensor_split(order, size_buckets):
+            for part in torch.tensor_split(order, max(size_buckets, 1)):
                 if part.numel() == 0:
                     continue
                 blocks = list(torch.split(part, cus))

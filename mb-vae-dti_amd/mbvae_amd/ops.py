@@ -350,15 +350,15 @@ def ln_residual(x, r, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
 
 
 def edge_tile_map(node_mask):
-    """uint8 [bs*n*n/32]: 1 where the tile of 32 consecutive pair rows (b,i,j) holds a valid pair, 0 where all of
-    them are padding; None when bs*n*n is not a multiple of 32.  Lets the inference kernels below skip padding tiles
-    of ragged batches (the mask is the same for every layer and every reverse-diffusion step)."""
-    bs, n = node_mask.shape
-    if (bs * n * n) % 32:
-        return None
+    """uint8 [ceil(bs*n*n/32)]: 1 where the tile of 32 consecutive pair rows (b,i,j) holds a valid pair, 0 where all
+    of them are padding.  Lets the inference kernels below skip padding tiles of ragged batches (the mask is the same
+    for every layer and every reverse-diffusion step)."""
     m = node_mask.bool()
-    pair = m.unsqueeze(1) & m.unsqueeze(2)
-    return pair.reshape(-1, 32).any(1).to(torch.uint8)
+    pair = (m.unsqueeze(1) & m.unsqueeze(2)).reshape(-1)
+    pad = -pair.numel() % 32
+    if pad:
+        pair = torch.cat((pair, pair.new_zeros(pad)))
+    return pair.view(-1, 32).any(1).to(torch.uint8)
 
 
 def zero_masked_pairs_(P, node_mask):
@@ -370,13 +370,13 @@ def zero_masked_pairs_(P, node_mask):
 
 def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5, tile_map=None):
     """LayerNorm(x + linear(relu(linear(x, w1, b1)), w2, b2)) * gamma + beta without gradients or dropout.
-    One fused kernel where the widths allow (64 -> 128 -> 64, rows % 32 == 0), else the three separate kernels.
+    One fused kernel where the widths allow (64 -> 128 -> 64), else the three separate kernels.
     tile_map (edge_tile_map): tiles marked 0 must consist of padding rows that all hold the same values; one of them
     is evaluated and copied to the rest (same bits as evaluating each)."""
     x = _f32c(x, "x")
     d, dff = x.shape[-1], w1.shape[0]
     rows = x.numel() // d
-    if tile_map is not None and tile_map.numel() * 32 != rows:
+    if tile_map is not None and tile_map.numel() != (rows + 31) // 32:
         raise ValueError("tile_map does not match the number of rows")
     with torch.no_grad():
         out = torch.empty_like(x)
@@ -389,13 +389,13 @@ def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5, tile_map=None):
 
 def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5, tile_map=None):
     """LayerNorm(E + edge_mask * linear(P, w, b)) * gamma + beta without gradients or dropout: one fused kernel
-    where the widths allow (256 -> 64, rows % 32 == 0), else the projection and the residual LayerNorm kernels.
+    where the widths allow (256 -> 64), else the projection and the residual LayerNorm kernels.
     P is only read on valid pairs (it may be uninitialised elsewhere); tile_map (edge_tile_map) lets whole padding
     tiles go unfetched."""
     P, E = _f32c(P, "P"), _f32c(E, "E")
     dx, de = P.shape[-1], E.shape[-1]
     rows = E.numel() // de
-    if tile_map is not None and tile_map.numel() * 32 != rows:
+    if tile_map is not None and tile_map.numel() != (rows + 31) // 32:
         raise ValueError("tile_map does not match the number of rows")
     with torch.no_grad():
         out = torch.empty_like(E)

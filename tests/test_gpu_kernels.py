@@ -502,6 +502,11 @@ def test_full_model_sampling_and_val_step_run():
     for grp, n in zip(groups, (9, 4, 6)):
         for atoms, bonds in grp:
             assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
+    groups = model.sample_batch(emb, num_nodes=torch.tensor([9, 4, 6]), num_samples_per_embedding=2, return_graphs=True,
+                                balance=True)
+    for grp, n in zip(groups, (9, 4, 6)):
+        for atoms, bonds in grp:
+            assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
     # one reverse step captured as a HIP graph and replayed: same contract
     groups = model.sample_batch(emb, num_nodes=torch.tensor([9, 4, 6]), num_samples_per_embedding=2, return_graphs=True,
                                 use_graph=True)
@@ -764,7 +769,7 @@ def test_grad_sync_rccl_world1_matches_plain_step():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows", [32, 4 * 37 * 37 // 32 * 32, 3 * 64 * 64])
+@pytest.mark.parametrize("rows", [32, 4 * 37 * 37 // 32 * 32, 3 * 64 * 64, 5, 3 * 37 * 37, 32 * 2048 * 3 + 7])
 def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
     """Inference-only fused edge feed-forward + LayerNorm (64 -> 128 -> 64): against plain torch and against the
     three separate kernels."""
@@ -779,12 +784,12 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
     assert_close(got, ref, what="fused ffn + LN")
     # padding tiles: every row of a tile marked 0 holds the same values; the result must not change by a bit
     if rows >= 64:
-        tiles = rows // 32
+        tiles = (rows + 31) // 32
         tm = (torch.rand(tiles, generator=g) < 0.5).to(torch.uint8)
         tm[0], tm[-1] = 1, 0
-        xp = x.clone().view(tiles, 32, 64)
+        xp = torch.cat((x, x[:tiles * 32 - rows])).view(tiles, 32, 64).clone()
         xp[tm == 0] = x[5]
-        xp = xp.view(rows, 64).cuda()
+        xp = xp.view(-1, 64)[:rows].contiguous().cuda()
         full = ops.ffn_ln_inference(xp, *dv[1:], 1e-5)
         skip = ops.ffn_ln_inference(xp, *dv[1:], 1e-5, tile_map=tm.cuda())
         assert torch.equal(full, skip), "padding-tile shortcut changed the result"
@@ -796,7 +801,8 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
     assert_close(got, sep, rtol=3e-6, what="fused vs separate")
 
 
-@pytest.mark.parametrize("bs,n,sizes", [(2, 64, None), (2, 32, (32, 9)), (8, 20, (20, 3, 11, 20, 1, 7, 19, 2))])
+@pytest.mark.parametrize("bs,n,sizes", [(2, 64, None), (2, 32, (32, 9)), (8, 20, (20, 3, 11, 20, 1, 7, 19, 2)),
+                                        (3, 9, (9, 4, 7)), (5, 57, (57, 20, 8, 33, 41)), (1, 3, None)])
 def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
     """Inference-only e_out + residual + LayerNorm (256 -> 64, edge-masked projection): against plain torch and the
     separate kernels."""
@@ -816,7 +822,9 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
     Pn = P.clone()
     Pn[~em.bool().expand_as(P)] = float("nan")
     tm = ops.edge_tile_map(mask.cuda())
-    assert tm is not None and int(tm.sum()) == int(em.reshape(-1, 32).any(1).sum())
+    flat = em.reshape(-1).bool()
+    flat = torch.cat((flat, flat.new_zeros(-flat.numel() % 32)))
+    assert int(tm.sum()) == int(flat.view(-1, 32).any(1).sum())
     got2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:], tile_map=tm)
     assert torch.equal(got2, got), "masked pairs of P leaked into the result"
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
