@@ -12,10 +12,10 @@
 //
 // Forward: one wave per query row (b,i), online (running max / sum) softmax over j; also stores
 // lse = max + log(sum) per (b,i,c) so that backward can rebuild A without a second reduction.
-// Backward: every (i,j,c) element is independent once lse and wV are known.  One 1024-thread
-// workgroup per graph: wave w owns keys j = w, w+16, ... (dK/dV accumulate in registers over the
-// i loop, no cross-workgroup reduction), the per-query sums dQ[i] are combined across the 16 waves
-// with LDS float adds.
+// Backward: every (i,j,c) element is independent once lse and wV are known.  One 512-thread
+// workgroup per (graph, 16 keys): a wave owns two keys (dK/dV accumulate in registers over the
+// i loop), the per-query sums dQ[i] are combined across the 8 waves with LDS float adds and across
+// the key groups with global float adds.
 #include "common.h"
 
 
@@ -109,11 +109,14 @@ __global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
   st4(lse + (node + i) * dx + c, s);
 }
 
-// grid: (ceil(dx/256), ceil(n/32), bs), block 1024: wave w owns keys j = 32*blockIdx.y + w + 16*jj (jj < 2),
-// lane = 4 channels.  dQ/dye_* are accumulated with global float adds across the key groups (zeroed by the host).
+// grid: (ceil(dx/256), ceil(n/KPB), bs), block 64*NW: wave w owns keys j = KPB*blockIdx.y + w + NW*jj (jj < 2, KPB =
+// 2*NW keys per block), lane = 4 channels.  dQ/dye_* are accumulated with global float adds across the key groups
+// (zeroed by the host).  Block shape (measured at bs=256, n=64, dx=256): 8 waves x 32 query rows per LDS pass keeps
+// three independent workgroups on a CU and runs 14 % faster than one 16-wave workgroup with 64 rows; requesting the
+// next query row's streams ahead of the arithmetic (two rows in flight per wave) did not help at either shape.
 #define EA_JPW 2
-#define EA_ROWS 64
-__global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
+template <int NW, int ROWS>
+__global__ __launch_bounds__(64 * NW) void edge_attn_bwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ E1, const float* __restrict__ E2,
     const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
@@ -122,96 +125,109 @@ __global__ __launch_bounds__(1024) void edge_attn_bwd_kernel(
     float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dQ, float* __restrict__ dK,
     float* __restrict__ dV, float* __restrict__ dye_add, float* __restrict__ dye_mul, int n, int dx, float scale,
     int ldq, int lde) {
-  __shared__ float dq_acc[EA_ROWS * 256];
+  constexpr int KPB = NW * EA_JPW, NT = 64 * NW;
+  __shared__ float dq_acc[ROWS * 256];
   __shared__ float dya_acc[256], dym_acc[256];
-  // V rows of this block's 32 keys: re-read for every query row; from global memory they get evicted from L1/L2 by
+  // V rows of this block's keys: re-read for every query row; from global memory they get evicted from L1/L2 by
   // the edge streams in between and come back from HBM (measured: +1 GB of fetches per launch)
-  __shared__ __align__(16) float v_rows[32 * 256];
+  __shared__ __align__(16) float v_rows[KPB * 256];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addressing on the scalar unit
   const int b = blockIdx.z;
   const int c = blockIdx.x * 256 + lane * 4;
   const int cbase = blockIdx.x * 256;
   const bool active = c < dx;
+  const int cc = active ? c : 0;                   // inactive lanes load from channel 0 and store nothing
   const int64_t node = (int64_t)b * n;
   if (threadIdx.x < 256) { dya_acc[threadIdx.x] = 0.f; dym_acc[threadIdx.x] = 0.f; }
 
   float4 ks[EA_JPW], dk[EA_JPW], dv[EA_JPW];
-  bool ok[EA_JPW];
+  bool ok[EA_JPW], inr[EA_JPW];
+  int jc[EA_JPW];
   float4 ym = make_float4(1.f, 1.f, 1.f, 1.f);
   float4 dya = make_float4(0.f, 0.f, 0.f, 0.f), dym = dya;
 #pragma unroll
   for (int jj = 0; jj < EA_JPW; ++jj) {
-    const int j = blockIdx.y * 32 + wave + 16 * jj;
-    dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj]; ks[jj] = dk[jj]; ok[jj] = false;
-    if (active && j < n) {
-      const float4 k = ld4(K + (node + j) * ldq + c);
-      st4(&v_rows[(wave + 16 * jj) * 256 + lane * 4], ld4(V + (node + j) * ldq + c));   // read back by this lane only
-      F4_OP(ks[jj], f4get(k, _q) * scale);
-      ok[jj] = mask[node + j] != 0;
-    }
+    const int j = blockIdx.y * KPB + wave + NW * jj;
+    inr[jj] = j < n;
+    jc[jj] = min(j, n - 1);
+    dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj];
+    const float4 k = ld4(K + (node + jc[jj]) * ldq + cc);
+    st4(&v_rows[(wave + NW * jj) * 256 + lane * 4], ld4(V + (node + jc[jj]) * ldq + cc));   // read back by this lane only
+    F4_OP(ks[jj], f4get(k, _q) * scale);
+    ok[jj] = inr[jj] && mask[node + jc[jj]] != 0;
   }
-  if (active) {
-    const float4 t = ld4(ye_mul + (int64_t)b * dx + c);
+  {
+    const float4 t = ld4(ye_mul + (int64_t)b * dx + cc);
     ym.x += t.x; ym.y += t.y; ym.z += t.z; ym.w += t.w;
   }
 
-  for (int i0 = 0; i0 < n; i0 += EA_ROWS) {
-    const int rows = min(EA_ROWS, n - i0);
-    for (int t = threadIdx.x; t < rows * 256; t += 1024) dq_acc[t] = 0.f;
+  float4 e1[1][EA_JPW], e2[1][EA_JPW], dp[1][EA_JPW], q4[1], ls4[1], wv4[1], dwv4[1];
+#define EA_LOAD(i_, S)                                                                     \
+  {                                                                                        \
+    const int64_t nrow = node + min((i_), n - 1);                                          \
+    q4[S] = ld4(Q + nrow * ldq + cc);                                                      \
+    ls4[S] = ld4(lse + nrow * dx + cc);                                                    \
+    wv4[S] = ld4(wV + nrow * dx + cc);                                                     \
+    dwv4[S] = ld4(dwV + nrow * dx + cc);                                                   \
+    _Pragma("unroll") for (int jj = 0; jj < EA_JPW; ++jj) {                                \
+      e1[S][jj] = ld4s(E1 + (nrow * n + jc[jj]) * (int64_t)lde + cc);                      \
+      e2[S][jj] = ld4s(E2 + (nrow * n + jc[jj]) * (int64_t)lde + cc);                      \
+      dp[S][jj] = ld4s(dP + (nrow * n + jc[jj]) * (int64_t)dx + cc);                       \
+    }                                                                                      \
+    asm volatile("" : : : "memory");         /* issue the loads here */                    \
+  }
+#define EA_ROW(i_, ii_, S)                                                                 \
+  {                                                                                        \
+    const float4 q = q4[S], ls = ls4[S], wv = wv4[S], dwv = dwv4[S];                       \
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+    const int64_t nrow = node + (i_);                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < EA_JPW; ++jj) {                                \
+      const float4 x1 = e1[S][jj], x2 = e2[S][jj], dpp = dp[S][jj];                        \
+      const float4 vj = ld4(&v_rows[(wave + NW * jj) * 256 + lane * 4]);                   \
+      float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));                              \
+      float4 y; F4_OP(y, f4get(qk, _q) * (f4get(x1, _q) + 1.f) + f4get(x2, _q));           \
+      float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);             \
+      float4 dy; F4_OP(dy, f4get(dpp, _q) * f4get(ym, _q) +                                \
+                             f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q))); \
+      if (inr[jj] && active) {                                                             \
+        float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));                                 \
+        st4s(dE1 + (nrow * n + jc[jj]) * (int64_t)lde + c, t);                             \
+        st4s(dE2 + (nrow * n + jc[jj]) * (int64_t)lde + c, dy);                            \
+        float4 g; F4_OP(g, f4get(dy, _q) * (f4get(x1, _q) + 1.f));                         \
+        F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));                       \
+        F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);            \
+        F4_OP(dv[jj], f4get(dv[jj], _q) + f4get(a, _q) * f4get(dwv, _q));                  \
+        F4_OP(dya, f4get(dya, _q) + f4get(dpp, _q));                                       \
+        F4_OP(dym, f4get(dym, _q) + f4get(dpp, _q) * f4get(y, _q));                        \
+      }                                                                                    \
+    }                                                                                      \
+    float* slot = &dq_acc[(ii_) * 256 + lane * 4];                                         \
+    atomicAdd(slot + 0, dq.x); atomicAdd(slot + 1, dq.y); atomicAdd(slot + 2, dq.z); atomicAdd(slot + 3, dq.w); \
+  }
+
+  for (int i0 = 0; i0 < n; i0 += ROWS) {
+    const int rows = min(ROWS, n - i0);
+    for (int t = threadIdx.x; t < rows * 256; t += NT) dq_acc[t] = 0.f;
     __syncthreads();
-    if (active) {
 #pragma unroll 1
-      for (int ii = 0; ii < rows; ++ii) {
-        const int i = i0 + ii;
-        const float4 q = ld4(Q + (node + i) * ldq + c);
-        const float4 ls = ld4(lse + (node + i) * dx + c);
-        const float4 wv = ld4(wV + (node + i) * dx + c);
-        const float4 dwv = ld4(dwV + (node + i) * dx + c);
-        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int64_t rowbase = ((node + i) * n) * (int64_t)dx + c;
-        const int64_t erow = ((node + i) * n) * (int64_t)lde + c;
-#pragma unroll
-        for (int jj = 0; jj < EA_JPW; ++jj) {
-          const int j = blockIdx.y * 32 + wave + 16 * jj;
-          if (j < n) {
-            const int64_t off = rowbase + (int64_t)j * dx;
-            const int64_t eoff = erow + (int64_t)j * lde;
-            const float4 e1 = ld4s(E1 + eoff);
-            const float4 e2 = ld4s(E2 + eoff);
-            const float4 dp = ld4s(dP + off);
-            const float4 vj = ld4(&v_rows[(wave + 16 * jj) * 256 + lane * 4]);
-            float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));
-            float4 y; F4_OP(y, f4get(qk, _q) * (f4get(e1, _q) + 1.f) + f4get(e2, _q));
-            float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);
-            float4 dy; F4_OP(dy, f4get(dp, _q) * f4get(ym, _q) +
-                                   f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q)));
-            float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));
-            st4s(dE1 + eoff, t);
-            st4s(dE2 + eoff, dy);
-            float4 g; F4_OP(g, f4get(dy, _q) * (f4get(e1, _q) + 1.f));
-            F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));
-            F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);
-            F4_OP(dv[jj], f4get(dv[jj], _q) + f4get(a, _q) * f4get(dwv, _q));
-            F4_OP(dya, f4get(dya, _q) + f4get(dp, _q));
-            F4_OP(dym, f4get(dym, _q) + f4get(dp, _q) * f4get(y, _q));
-          }
-        }
-        float* slot = &dq_acc[ii * 256 + lane * 4];
-        atomicAdd(slot + 0, dq.x); atomicAdd(slot + 1, dq.y); atomicAdd(slot + 2, dq.z); atomicAdd(slot + 3, dq.w);
-      }
+    for (int ii = 0; ii < rows; ++ii) {
+      EA_LOAD(i0 + ii, 0)
+      EA_ROW(i0 + ii, ii, 0)
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < rows * 256; t += 1024) {
-      const int ii = t >> 8, cc = t & 255;
-      if (cbase + cc < dx) atomicAdd(&dQ[(node + i0 + ii) * ldq + cbase + cc], dq_acc[t]);
+    for (int t = threadIdx.x; t < rows * 256; t += NT) {
+      const int ii = t >> 8, ch = t & 255;
+      if (cbase + ch < dx) atomicAdd(&dQ[(node + i0 + ii) * ldq + cbase + ch], dq_acc[t]);
     }
     __syncthreads();
   }
+#undef EA_LOAD
+#undef EA_ROW
   if (active) {
 #pragma unroll
     for (int jj = 0; jj < EA_JPW; ++jj) {
-      const int j = blockIdx.y * 32 + wave + 16 * jj;
+      const int j = blockIdx.y * KPB + wave + NW * jj;
       if (j < n) { st4(dK + (node + j) * ldq + c, dk[jj]); st4(dV + (node + j) * ldq + c, dv[jj]); }
     }
     atomicAdd(&dya_acc[lane * 4 + 0], dya.x); atomicAdd(&dya_acc[lane * 4 + 1], dya.y);
@@ -263,7 +279,7 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
   if (ldq < dx || lde < dx || (ldq & 3) || (lde & 3) || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
-  if (bs > 65535 || n > 32 * 65535) return MBVAE_EUNSUPPORTED;
+  if (bs > 65535 || n > 16 * 65535) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};
   for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
@@ -272,9 +288,11 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
   if (hipMemsetAsync(dQ, 0, sizeof(float) * ((bs * n - 1) * ldq + dx), stream) != hipSuccess) return MBVAE_ELAUNCH;
   if (hipMemsetAsync(dye_add, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
   if (hipMemsetAsync(dye_mul, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
-  dim3 grid((unsigned)((dx + 255) / 256), (unsigned)((n + 31) / 32), (unsigned)bs);
-  hipLaunchKernelGGL(edge_attn_bwd_kernel, grid, dim3(1024), 0, stream, Q, K, V, E1, E2, ye_mul, mask, wV, lse,
-                     dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale, (int)ldq, (int)lde);
+  constexpr int NW = 8, ROWS = 32;
+  dim3 grid((unsigned)((dx + 255) / 256), (unsigned)((n + 2 * NW - 1) / (2 * NW)), (unsigned)bs);
+  hipLaunchKernelGGL((edge_attn_bwd_kernel<NW, ROWS>), grid, dim3(64 * NW), 0, stream, Q, K, V, E1, E2, ye_mul, mask,
+                     wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale, (int)ldq,
+                     (int)lde);
   return mbvae_launch_status();
 }
 
