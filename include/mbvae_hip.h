@@ -78,11 +78,15 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
  * is not NULL (the backward entry points read it); with NULL nothing of that size is written, P is only written
  * for valid (query, key) pairs (the rest of the buffer keeps whatever it held) and tiles without a valid pair cost
  * nothing: the inference form, whose P feeds mbvae_edge_out_ln_fwd.
+ * work_counter (NULL, or one int32 in device memory that the call zeroes on `stream` and then owns until the kernel
+ * ends): the workgroups draw their (graph, block of query rows) tasks from it first come first served, which evens
+ * out ragged batches; with NULL the tasks are dealt round robin.  Calls that overlap on one device need separate
+ * counters.  The results do not depend on the order.
  * MBVAE_EUNSUPPORTED unless de == 64, dx == 256 and n <= 64: callers then use the two separate entry points. */
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
-                         float* P, float* wV, float* lse, float* E12, int64_t bs, int64_t n, int64_t de, int64_t dx,
-                         float scale, mbvae_stream_t stream);
+                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, int64_t bs, int64_t n,
+                         int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
 
 /* ---- edge feed-forward block, inference form ----------------------------------------------------------
  * Replaces `normE2(E + linE2(relu(linE1(E))))` of XEyTransformerLayer.forward (graph_transformer.py:139-142) when

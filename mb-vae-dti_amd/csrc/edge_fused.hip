@@ -24,6 +24,7 @@ struct EdgeFusedArgs {
   const float* ye_add; const float* ye_mul; const uint8_t* mask;
   float* P; float* wV; float* lse; float* E12;
   int bs, n; float scale; int ichunks;
+  int* queue;      // optional work counter (zeroed before the launch): workgroups take tasks in order as they finish
 };
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -61,7 +62,20 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   float qv[2];
   float m_run = -INFINITY, l_run = 0.f, av_run = 0.f;
 
-  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+  // Task order: static round robin, or (with a queue) first come first served -- graphs of a ragged batch cost
+  // very different amounts, and a workgroup that drew small ones simply takes more of them.  Every workgroup leaves
+  // through the same test (task >= ntasks), so the grid always drains.
+  __shared__ int next_task;
+  for (int task = blockIdx.x, round = 0;; ++round) {
+    if (a.queue) {
+      __syncthreads();                             // everyone has read the previous value
+      if (tid == 0) next_task = atomicAdd(a.queue, 1);
+      __syncthreads();
+      task = next_task;
+    } else if (round > 0) {
+      task += gridDim.x;
+    }
+    if (task >= ntasks) break;
     const int b = task / a.ichunks, ic = task - b * a.ichunks;
     const int i0 = ic * ipc, i1 = min(n, i0 + ipc);
     const int64_t node = (int64_t)b * n;
@@ -514,11 +528,13 @@ extern "C" {
 // E [bs,n,n,de] dense, W12 [2dx,de] (rows 0..dx-1: e_mul, dx..2dx-1: e_add), b12 [2dx] or null; Q,K,V [bs,n,dx]
 // rows ldq floats apart; ye_add, ye_mul [bs,dx]; mask [bs,n].  Outputs P [bs,n,n,dx], wV, lse [bs,n,dx] dense, and,
 // when E12 is not null, the projection output E1|E2 [bs,n,n,2dx] (what the backward kernels read).
+// work_counter: NULL, or one int32 of device memory the call may overwrite (it is zeroed on `stream` first): the
+// workgroups then draw (graph, query-row block) tasks from it in order instead of a fixed round robin.
 // MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
-                         float* P, float* wV, float* lse, float* E12, int64_t bs, int64_t n, int64_t de, int64_t dx,
-                         float scale, hipStream_t stream) {
+                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, int64_t bs, int64_t n,
+                         int64_t de, int64_t dx, float scale, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -536,7 +552,15 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
     const double eff = (double)tasks / (double)(((tasks + cus - 1) / cus) * cus);
     if (eff > best + 0.02) { best = eff; ichunks = cand; }
   }
-  EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks};
+  if (work_counter) {
+    // dynamic order: about four tasks per workgroup are enough to even out a ragged batch
+    ichunks = 1;
+    while (ichunks < 8 && 2 * ichunks <= n && bs * ichunks < 4 * (int64_t)cus) ichunks *= 2;
+    if (((uintptr_t)work_counter & 3) || hipMemsetAsync(work_counter, 0, sizeof(int32_t), stream) != hipSuccess)
+      return MBVAE_EINVAL;
+  }
+  EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
+                  work_counter};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;

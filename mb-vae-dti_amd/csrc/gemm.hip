@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     if (A_KC) {
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
-        const int row = m0 + (tid >> 3) + 32 * p, kc = kt + (tid & 7) * 4;
+        // FAST allows a ragged last M-tile for this layout: its surplus rows re-read row M-1 and are never stored
+        const int row = FAST ? min(m0 + (tid >> 3) + 32 * p, g.M - 1) : m0 + (tid >> 3) + 32 * p, kc = kt + (tid & 7) * 4;
         const int64_t off = (int64_t)row * g.lda + kc;
         load4(g.A, vecA, off, row < g.M, kc, kend, &ra[p * 4]);
         if (has_gate) load4(g.a_gate, vecA, off, row < g.M, kc, kend, &rg[p * 4]);
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-      if (!FAST && row >= g.M) continue;
+      if (row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + r;
@@ -1114,7 +1115,8 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)splits), block(256);
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
-  const bool fast = aligned && g.M % BM == 0 && g.N % BN == 0 && g.K % 32 == 0;
+  // branch-free operand loads: whole N and K tiles; M may be ragged when A is [M,K] (rows are clamped, see fetch)
+  const bool fast = aligned && (A_KC || g.M % BM == 0) && g.N % BN == 0 && g.K % 32 == 0;
   const bool gate = g.a_gate != nullptr;
 #define GEMM_LAUNCH(bm, bn, wm, wn)                                                                                     \
   do {                                                                                                                   \

@@ -62,12 +62,24 @@ class NodeEdgeBlock(nn.Module):
         self.x_out, self.e_out = nn.Linear(dx, dx), nn.Linear(dx, de)
         self.y_out = nn.Sequential(nn.Linear(dy, dy), nn.ReLU(), nn.Linear(dy, dy))
 
-    @staticmethod
-    def _fused(x, layers, **kw):
-        """One product for several Linear layers that read the same input: outputs side by side in the last dim.
-        (The concatenated weight is rebuilt from the layers' own parameters every call; autograd splits its gradient.)"""
-        w = torch.cat([l.weight for l in layers], 0)
-        b = torch.cat([l.bias for l in layers], 0)
+    def _stacked(self, key, layers):
+        """Weights and biases of several Linear layers side by side.  With gradients they are rebuilt from the layers'
+        own parameters every call (autograd splits the gradient); without, the copy is kept until a parameter changes
+        (in-place updates and load_state_dict bump the tensors' version counters; .data swaps change data_ptr)."""
+        if torch.is_grad_enabled():
+            return torch.cat([l.weight for l in layers], 0), torch.cat([l.bias for l in layers], 0)
+        stamp = tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight, l.bias))
+        cache = self.__dict__.setdefault("_stack_cache", {})
+        hit = cache.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, torch.cat([l.weight for l in layers], 0), torch.cat([l.bias for l in layers], 0))
+            cache[key] = hit
+        return hit[1], hit[2]
+
+    def _fused(self, key, x, layers, **kw):
+        """One product for several Linear layers that read the same input: outputs side by side in the last dim."""
+        w, b = self._stacked(key, layers)
         return ops.linear(x, w, b, **kw)
 
     def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None):
@@ -77,10 +89,9 @@ class NodeEdgeBlock(nn.Module):
         dx = self.dx
         node = dict(mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
         edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
-        QKV = self._fused(X, (self.q, self.k, self.v), **node)                   # [bs,n,3dx]
-        w12 = torch.cat((self.e_mul.weight, self.e_add.weight), 0)
-        b12 = torch.cat((self.e_mul.bias, self.e_add.bias), 0)
-        yp = self._fused(y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
+        QKV = self._fused("qkv", X, (self.q, self.k, self.v), **node)            # [bs,n,3dx]
+        w12, b12 = self._stacked("e12", (self.e_mul, self.e_add))
+        yp = self._fused("y5", y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head)
@@ -92,7 +103,11 @@ class NodeEdgeBlock(nn.Module):
             if not P.requires_grad and not torch.is_grad_enabled():
                 ops.zero_masked_pairs_(P, node_mask)      # the no-gradient attention forward skips padding pairs
             newE = _lin(self.e_out, P, **edge)
-        newX = _lin(self.x_out, yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV, **node)
+        if torch.is_grad_enabled():
+            film = yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV
+        else:                                  # same arithmetic in two element-wise kernels instead of three
+            film = torch.addcmul(yx_add.unsqueeze(1), yx_mul.unsqueeze(1) + 1, wV)
+        newX = _lin(self.x_out, film, **node)
         new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)
         new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
         return (newX, newE, new_y, E_alias) if return_edge_alias else (newX, newE, new_y)

@@ -32,6 +32,19 @@ def workspace(device, nbytes=96 << 20):
     return ws
 
 
+_queue_cache = {}
+
+
+def _work_counter(device):
+    """One int32 per device for kernels that hand out their tasks through a counter (they run serialised on the stream
+    and zero it themselves)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    q = _queue_cache.get(key)
+    if q is None:
+        q = _queue_cache[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return q
+
+
 def _f32c(t, name="tensor"):
     if not t.is_cuda or t.dtype != torch.float32:
         raise RuntimeError(f"{name}: expected a float32 tensor on the GPU (got {t.dtype} on {t.device}); "
@@ -272,7 +285,8 @@ class _EdgeBlock(torch.autograd.Function):
         q = QKV.data_ptr()
         fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
                           ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
-                          _ptr(E12), bs, n, de, dx, scale, _stream(), allow_unsupported=True)
+                          _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(), bs, n, de, dx, scale, _stream(),
+                          allow_unsupported=True)
         if not fused:
             if E12 is None:
                 E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev)
