@@ -55,13 +55,17 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts) {
-  const int c = threadIdx.x;
-  if (c >= 2 + CE_MAX_C) return;
-  // pairwise-ish: accumulate in double to make the (deterministic) sum insensitive to nparts
-  double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * (2 + CE_MAX_C) + c];
-  out[c] = (float)s;
+// Sums the per-block partials column by column: 16 waves, wave w owns columns w and w + 16; every lane adds a strided
+// subset in double, then a fixed xor tree joins the lanes (same order every run, insensitive to nparts).
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < 2 + CE_MAX_C; c += 16) {
+    double s = 0.0;
+    for (int p = lane; p < nparts; p += 64) s += (double)part[(int64_t)p * (2 + CE_MAX_C) + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[c] = (float)s;
+  }
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ target,
@@ -108,11 +112,13 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ m
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void kl_finalize_kernel(const float* __restrict__ part, float* __restrict__ kl, int nparts, float scale) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void kl_finalize_kernel(const float* __restrict__ part, float* __restrict__ kl, int nparts, float scale) {
+  const int lane = threadIdx.x;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)part[p];
-  kl[0] = (float)(s * scale);
+  for (int p = lane; p < nparts; p += 64) s += (double)part[p];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) kl[0] = (float)(s * scale);
 }
 
 // dmu = dz + dkl*mu/numel ; dlogvar = dz*eps*0.5*exp(0.5 lv) + dkl*0.5*(exp(lv)-1)/numel
@@ -141,7 +147,7 @@ int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, in
   if (ws_bytes < mbvae_masked_ce_workspace()) return MBVAE_EINVAL;
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 1024);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, target, (float*)workspace, rows, (int)C);
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, out, blocks);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, out, blocks);
   return mbvae_launch_status();
 }
 
