@@ -99,8 +99,9 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
  * where padding pairs enter as zeros and only pass through row-wise operations -- so the kernel evaluates one of them
  * per wave and stores that result to the others without reading them.  The output is bit-identical to tile_ok = NULL. */
 int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                       const float* gamma, const float* beta, float* out, const uint8_t* tile_ok, int64_t M, int64_t d,
-                       int64_t dff, float eps, mbvae_stream_t stream);
+                       const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
+                       const int32_t* row_idx, const int32_t* nvalid, int64_t M, int64_t d, int64_t dff, float eps,
+                       mbvae_stream_t stream);
 
 /* Inference form of `normE1(E + e_out(newE))` (graph_transformer.py:251-252 followed by :133-134): out [M,de] =
  * LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta, P [M,dx], W [de,dx] (torch Linear layout), b [de] or NULL,
@@ -108,10 +109,20 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
  * MBVAE_EUNSUPPORTED unless dx == 256, de == 64: callers then use mbvae_linear_fwd + mbvae_ln_residual_fwd.
  * P is only read where keep(row) holds: rows of masked pairs may be uninitialised (mbvae_edge_fused_fwd without E12
  * does not write them).  tile_ok (NULL, or ceil(M/32) bytes): a 0 marks a tile of 32 consecutive rows without any kept
- * row; its P rows are not even fetched.  The output is bit-identical to tile_ok = NULL. */
+ * row; its P rows are not even fetched.  uniform_padding != 0 adds the caller's guarantee that every row of E in such
+ * tiles holds the same values (as for mbvae_edge_ffn_fwd): one of them is normalised per wave and the result stored
+ * to the others without reading them.  The output is bit-identical to tile_ok = NULL either way. */
 int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
                           int64_t n, const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
-                          int64_t M, int64_t dx, int64_t de, float eps, mbvae_stream_t stream);
+                          const int32_t* row_idx, const int32_t* nvalid, int uniform_padding, int64_t M, int64_t dx,
+                          int64_t de, float eps, mbvae_stream_t stream);
+
+/* Packed row order, the alternative to tile_ok for both entry points above (pass tile_ok = NULL with it; M >= 32):
+ * nvalid[0] = number of valid rows (a device int32, so that no host synchronisation is needed to build it);
+ * row_idx (int32, at least M + 64 entries) = the valid rows in ascending order, padded to a multiple of 32 by
+ * repeating the last one, followed by the padding rows, padded likewise.  The kernels then form their 32-row tiles
+ * from row_idx, so products are only spent on valid rows; the padding rows are treated as under tile_ok = 0.
+ * mbvae_amd.ops.edge_row_order(node_mask) builds both.  Same bits as the natural order. */
 
 /* ---- residual + dropout + LayerNorm ------------------------------------------------------------------
  * Replaces `norm(X + dropout(newX))` of graph_transformer.py:125-144 (and nn.LayerNorm elsewhere with r = NULL). */

@@ -253,14 +253,56 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
 struct EdgeFfnArgs {
   const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
   const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
+  const int32_t* row_idx; const int32_t* nvalid;   // packed row order (see ef_row_order), or null
 };
+
+// Packed row order for ragged batches (optional, both kernels below): row_idx lists the nvalid[0] valid rows, padded
+// to a multiple of 32 by repeating the last one, then the M - nvalid[0] padding rows, padded likewise.  Tile t of the
+// kernels is then rows row_idx[32t .. 32t+31] instead of rows 32t .. 32t+31: valid rows fill whole tiles (no products
+// are spent on padding rows that merely share a tile with valid ones) and the padding tiles follow.  Repeated
+// entries are evaluated and stored twice with the same values.
+struct EfRowOrder {
+  const int32_t* idx; int64_t nvt, ntiles;
+  __device__ __forceinline__ EfRowOrder(const int32_t* row_idx, const int32_t* nvalid, int64_t M) : idx(row_idx) {
+    if (row_idx) {
+      const int64_t nv = nvalid[0];
+      nvt = (nv + 31) / 32;
+      ntiles = nvt + (M - nv + 31) / 32;
+    } else {
+      nvt = 0;
+      ntiles = (M + 31) / 32;       // the last tile may be partial: loads clamp, stores are guarded
+    }
+  }
+  // row of lane r in tile t, and whether it may be stored (always, in the packed order)
+  __device__ __forceinline__ int row(int64_t t, int r, int64_t M) const {
+    return idx ? idx[t * 32 + r] : (int)min(t * 32 + r, M - 1);
+  }
+  __device__ __forceinline__ bool inb(int64_t t, int r, int64_t M) const { return idx ? true : t * 32 + r < M; }
+};
+
+// Stores the 64-float row `cst` (LDS) to the 32 rows of a tile: 16 lanes per row, four whole rows per instruction
+// (the products' own layout, one row per lane, would write 32-byte pieces).  row / inb: lane r (< 32) holds the tile's
+// r-th row index and whether it may be written.
+__device__ __forceinline__ void ef_store_row_tile(float* out, const float* cst, int row, bool inb, int lane) {
+  const int sub = lane & 15, rr = lane >> 4;
+  const float4 cv = *reinterpret_cast<const float4*>(cst + sub * 4);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int src = it * 4 + rr;
+    const int rw = __shfl(row, src, 64);
+    const int ok = __shfl((int)inb, src, 64);
+    if (ok) *reinterpret_cast<float4*>(out + (int64_t)rw * 64 + sub * 4) = cv;
+  }
+}
 
 // Validity of the 32-row tiles a wave owns (tile k of the wave = global tile wid + k*nw), 64 at a time: one byte
 // gather + ballot per window; k only ever grows.  A null map marks every tile valid.
 struct EfTileWindow {
   unsigned long long bits = 0ull;
   int64_t base = -64;
-  __device__ __forceinline__ bool ok(const uint8_t* map, int64_t k, int64_t wid, int64_t nw, int64_t mine, int lane) {
+  __device__ __forceinline__ bool ok(const uint8_t* map, int64_t k, int64_t wid, int64_t nw, int64_t mine, int lane,
+                                     const EfRowOrder& ord) {
+    if (ord.idx) return wid + k * nw < ord.nvt;
     if (!map) return true;
     if (k >= base + 64) {
       base = k;
@@ -290,11 +332,15 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   if (tid < 64) { b2s[tid] = a.b2 ? a.b2[tid] : 0.f; gs[tid] = a.gamma[tid]; bs_[tid] = a.beta[tid]; }
   __syncthreads();
 
-  const int64_t ntiles = (a.M + 31) / 32;          // the last tile may be partial: loads clamp, stores are guarded
+  const EfRowOrder ord(a.row_idx, a.nvalid, a.M);
+  const int64_t ntiles = ord.ntiles;
   const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
   const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
   if (mine <= 0) return;
   float4 ra[2][8];
+  int srow[2];                                      // this lane's row in the staged tile
+  bool sinb[2];
+  int nxt_row = ord.row(wid, r, a.M);               // row of the NEXT tile to be fetched (its index load runs a tile ahead)
   // Tiles marked 0 in tile_ok hold padding rows, all with the same values (the caller's guarantee): the first one a
   // wave meets is evaluated like any other tile and its output row kept in LDS; the later ones only store that row.
   // mode: 0 = evaluate, 1 = evaluate and keep the row, 2 = store the kept row (its operand fetch is pointed at
@@ -307,24 +353,19 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   {                                                                                                   \
     const int64_t k = min((int64_t)(q), mine - 1);                                                     \
     int md = 0;                                                                                        \
-    if (!win.ok(a.tile_ok, k, wid, nw, mine, lane)) { md = have_cst ? 2 : 1; have_cst = true; }        \
+    if (!win.ok(a.tile_ok, k, wid, nw, mine, lane, ord)) { md = have_cst ? 2 : 1; have_cst = true; }   \
     mode[S] = md;                                                                                      \
-    const int64_t tile = md == 2 ? 0 : wid + k * nw;                                                   \
-    const float* src = a.x + min(tile * 32 + r, a.M - 1) * 64 + 32 * h;                                \
+    srow[S] = nxt_row;                                                                                 \
+    sinb[S] = ord.inb(wid + k * nw, r, a.M);                                                           \
+    nxt_row = ord.row(wid + min((int64_t)(q) + 1, mine - 1) * nw, r, a.M);                             \
+    const float* src = a.x + (int64_t)(md == 2 ? min(r, (int)a.M - 1) : srow[S]) * 64 + 32 * h;        \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
 #define FF_TILE(q, S)                                                                                 \
   if ((q) < mine && mode[S] == 2) {                                                                   \
-    const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
-    float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
-    if (tile * 32 + r < a.M)                                                                           \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
-      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                 \
-        *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) =                                           \
-            *reinterpret_cast<const float4*>(my_cst + 32 * u + 8 * gq + 4 * h);                        \
+    ef_store_row_tile(a.out, my_cst, srow[S], sinb[S], lane);                                          \
   } else if ((q) < mine) {                                                                            \
-    const int64_t tile = wid + (int64_t)(q) * nw;                                                      \
     /* a zero the optimiser cannot see through, added to the LDS indices of the small per-column vectors: their   \
        160 values are loop invariant and would otherwise be hoisted into registers, spilling the accumulators */ \
     int oz;                                                                                            \
@@ -357,8 +398,8 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
       }                                                                                                \
     }                                                                                                  \
     /* residual + LayerNorm: this lane has columns 32u + 8g + 4h + (0..3) of row `tile*32 + r` */      \
-    const bool inb = tile * 32 + r < a.M;                                                              \
-    const float* xrow = a.x + min(tile * 32 + r, a.M - 1) * 64 + 4 * h;                                \
+    const bool inb = sinb[S];                                                                          \
+    const float* xrow = a.x + (int64_t)srow[S] * 64 + 4 * h;                                           \
     float z[2][16];                                                                                    \
     float sum = 0.f;                                                                                   \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
@@ -375,7 +416,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
       _Pragma("unroll") for (int v = 0; v < 16; ++v) { z[u][v] -= mean; sq += z[u][v] * z[u][v]; }     \
     sq += __shfl_xor(sq, 32);                                                                          \
     const float rstd = rsqrtf(sq * (1.f / 64.f) + a.eps);                                              \
-    float* orow = a.out + (tile * 32 + r) * 64 + 4 * h;                                                \
+    float* orow = a.out + (int64_t)srow[S] * 64 + 4 * h;                                               \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
         const float4 gm = *reinterpret_cast<const float4*>(gs + 32 * u + 8 * gq + h4);              \
@@ -408,6 +449,8 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
 struct EdgeOutArgs {
   const float* P; const float* W; const float* b; const float* E; const uint8_t* mask; int n;
   const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
+  const int32_t* row_idx; const int32_t* nvalid;   // packed row order (EfRowOrder), or null
+  int uniform;     // the padding rows of E all hold the same values: one is evaluated per wave, the rest only stored
 };
 
 __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
@@ -417,6 +460,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
   float* bsv = Ws + 64 * LW;                        // [64]
   float* gs = bsv + 64;
   float* bt_ = gs + 64;
+  float* cst = bt_ + 64;                            // [8][64]: per wave, the output row shared by all padding rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -424,30 +468,54 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
   if (tid < 64) { bsv[tid] = a.b ? a.b[tid] : 0.f; gs[tid] = a.gamma[tid]; bt_[tid] = a.beta[tid]; }
   __syncthreads();
 
-  const int64_t ntiles = (a.M + 31) / 32;          // the last tile may be partial: loads clamp, stores are guarded
+  const EfRowOrder ord(a.row_idx, a.nvalid, a.M);
+  const int64_t ntiles = ord.ntiles;
   const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
   const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
   if (mine <= 0) return;
   const int64_t total = mine * 4;                   // 64-wide reduction groups of this wave
   float4 ra[2][8];
+  int srow[2];                                      // this lane's row in the staged tile
+  bool sinb[2];
   f32x16 yy[2];
-  // A tile marked 0 in tile_ok has no valid pair: its P rows are not read (the operand fetch is pointed at tile 0,
-  // which stays in cache, so that the fetch itself remains unconditional) and the products are skipped.
+  // A tile marked 0 in tile_ok (or past the valid tiles of the packed order) has no valid pair: its P rows are not
+  // read (the operand fetch is pointed at tile 0, which stays in cache, so that the fetch itself remains
+  // unconditional) and the products are skipped.  mode: 0 = valid tile; 3 = padding tile, each row normalised on
+  // its own; with a.uniform 1 = padding tile evaluated and its output row kept in LDS, 2 = only store the kept row.
   EfTileWindow win;
-  bool live[2] = {true, true};
+  int mode[2] = {0, 0};
+  int tile_mode = 0;
+  bool have_cst = false;
+  float* my_cst = cst + wave * 64;
+  // rows of the tile being fetched and of the one after it (its index load runs a tile ahead)
+  int cur_row = ord.row(wid, r, a.M), nxt_row = ord.row(wid + min((int64_t)1, mine - 1) * nw, r, a.M);
 #define EO_FETCH(q, S)                                                                                \
   {                                                                                                   \
     const int64_t qq = min((int64_t)(q), total - 1);                                                   \
-    live[S] = win.ok(a.tile_ok, qq >> 2, wid, nw, mine, lane);                                         \
-    const int64_t tile = live[S] ? wid + (qq >> 2) * nw : 0;                                           \
-    const float* src = a.P + min(tile * 32 + r, a.M - 1) * 256 + (qq & 3) * 64 + 32 * h;               \
+    if ((qq & 3) == 0) {                               /* first group of a tile (no loads in here) */  \
+      tile_mode = 0;                                                                                   \
+      if (!win.ok(a.tile_ok, qq >> 2, wid, nw, mine, lane, ord)) {                                     \
+        tile_mode = !a.uniform ? 3 : have_cst ? 2 : 1;                                                 \
+        have_cst = have_cst || a.uniform;                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+    mode[S] = tile_mode;                                                                               \
+    srow[S] = cur_row;                                                                                 \
+    sinb[S] = ord.inb(wid + (qq >> 2) * nw, r, a.M);                                                   \
+    const float* src = a.P + (int64_t)(tile_mode == 0 ? cur_row : min(r, (int)a.M - 1)) * 256 + (qq & 3) * 64 + 32 * h; \
+    {                                                  /* step to the next group's tile */             \
+      const int64_t q1 = min(qq + 1, total - 1);                                                       \
+      cur_row = (q1 >> 2) != (qq >> 2) ? nxt_row : cur_row;                                            \
+      nxt_row = ord.row(wid + min((q1 >> 2) + 1, mine - 1) * nw, r, a.M);                              \
+    }                                                                                                  \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
 #define EO_GROUP(q, S)                                                                                \
-  if ((q) < total) {                                                                                  \
+  if ((q) < total && mode[S] == 2) {                                                                  \
+    if (((q) & 3) == 3) ef_store_row_tile(a.out, my_cst, srow[S], sinb[S], lane);                      \
+  } else if ((q) < total) {                                                                           \
     const int gi = (int)((q) & 3);                                                                     \
-    const int64_t tile = wid + ((q) >> 2) * nw;                                                        \
     int oz;          /* opaque zero: keeps the loop-invariant LDS values from being hoisted into registers */ \
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));                                                        \
     const int h4 = 4 * h + oz;                                                                         \
@@ -455,7 +523,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = bsv[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
     }                                                                                                  \
-    if (live[S])                                                                                       \
+    if (mode[S] == 0)                                                                                  \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
       float4 t4 = ra[S][p];                                                                            \
       asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
@@ -467,11 +535,11 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       }                                                                                                \
     }                                                                                                  \
     if (gi == 3) {                                   /* row finished: mask, residual, LayerNorm */     \
-      const bool inb = tile * 32 + r < a.M;                                                            \
-      const int64_t row = min(tile * 32 + r, a.M - 1);                                                 \
+      const bool inb = sinb[S];                                                                        \
+      const int64_t row = srow[S];                                                                     \
       unsigned ma, mb;                                                                                 \
       mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, row, a.n, a.P, ma, mb);  \
-      const bool keep = live[S] && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb);   \
+      const bool keep = mode[S] == 0 && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb); \
       const float* xrow = a.E + row * 64 + 4 * h;                                                      \
       float z[2][16];                                                                                  \
       float sum = 0.f;                                                                                 \
@@ -499,7 +567,9 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
           o.x = z[u][4 * gq + 0] * rstd * gm.x + bt.x; o.y = z[u][4 * gq + 1] * rstd * gm.y + bt.y;    \
           o.z = z[u][4 * gq + 2] * rstd * gm.z + bt.z; o.w = z[u][4 * gq + 3] * rstd * gm.w + bt.w;    \
           if (inb) *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = o;                             \
+          if (mode[S] == 1 && r == 0) *reinterpret_cast<float4*>(my_cst + 32 * u + 8 * gq + 4 * h) = o; \
         }                                                                                              \
+      if (mode[S] == 1) asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   /* the row is in LDS */ \
     }                                                                                                  \
   }
   EO_FETCH(0, 0)
@@ -573,18 +643,20 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
 // (torch Linear layouts), b1 / b2 may be NULL.  Forward only (no dropout): the inference form of the edge
 // feed-forward block.  MBVAE_EUNSUPPORTED unless d == 64 and dff == 128.
 int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
-                       const float* gamma, const float* beta, float* out, const uint8_t* tile_ok, int64_t M, int64_t d,
-                       int64_t dff, float eps, hipStream_t stream) {
+                       const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
+                       const int32_t* row_idx, const int32_t* nvalid, int64_t M, int64_t d, int64_t dff, float eps,
+                       hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0) return MBVAE_EINVAL;
   if (d != 64 || dff != 128 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {x, W1, W2, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
-  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok};
+  if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
+  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid};
   const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
   if (hipFuncSetAttribute((const void*)edge_ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;
-  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 7) / 8, ef_num_cus());
+  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
   hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
@@ -594,17 +666,19 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
 // inference form of e_out followed by normE1.  MBVAE_EUNSUPPORTED unless dx == 256, de == 64.
 int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const float* E, const uint8_t* mask,
                           int64_t n, const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
-                          int64_t M, int64_t dx, int64_t de, float eps, hipStream_t stream) {
+                          const int32_t* row_idx, const int32_t* nvalid, int uniform_padding, int64_t M, int64_t dx,
+                          int64_t de, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0 || (mask && n <= 0)) return MBVAE_EINVAL;
   if (dx != 256 || de != 64 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {P, W, E, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
-  EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok};
-  const size_t smem = sizeof(float) * (64 * 257 + 3 * 64);
+  if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
+  EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid, uniform_padding};
+  const size_t smem = sizeof(float) * (64 * 257 + 3 * 64 + 8 * 64);
   if (hipFuncSetAttribute((const void*)edge_out_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return MBVAE_ELAUNCH;
-  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 7) / 8, ef_num_cus());
+  const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
   hipLaunchKernelGGL(edge_out_ln_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }

@@ -5,6 +5,8 @@ mb_vae_dti/training/models/graph_transformer.py:70-343 (Xtoy, Etoy, XEyTransform
 GraphTransformer).  Parameters live in ordinary nn.Linear / nn.LayerNorm containers and are read in place
 by the kernels, so checkpoints load unchanged.  The reference's host-synchronising assert_* checks are dropped.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -82,7 +84,7 @@ class NodeEdgeBlock(nn.Module):
         w, b = self._stacked(key, layers)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
         use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input)."""
         n = X.shape[1]
@@ -98,7 +100,8 @@ class NodeEdgeBlock(nn.Module):
         if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
             ln, eps = edge_norm
             newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps,
-                                             tile_map=tile_map)
+                                             tile_map=tile_map, order=order,
+                                             uniform_padding=tile_map is not None or order is not None)
         else:
             if not P.requires_grad and not torch.is_grad_enabled():
                 ops.zero_masked_pairs_(P, node_mask)      # the no-gradient attention forward skips padding pairs
@@ -130,16 +133,18 @@ class XEyTransformerLayer(nn.Module):
         self.dropout_p = dropout
         self.eps = layer_norm_eps
 
-    def forward(self, X, E, y, node_mask, seeds=None, tile_map=None):
-        """tile_map (ops.edge_tile_map(node_mask), inference only): lets the fused edge kernels skip padding tiles.  It
-        relies on every padding pair row of E holding the same values, which holds for E as GraphTransformer feeds
-        it (padding rows enter as zeros and only pass through row-wise operations)."""
+    def forward(self, X, E, y, node_mask, seeds=None, tile_map=None, order=None):
+        """tile_map / order (ops.edge_tile_map / ops.edge_row_order of node_mask, inference only): let the fused edge
+        kernels skip or pack away the padding rows.  Both rely on every padding pair row of E holding the same values,
+        which holds for E as GraphTransformer feeds it (padding rows enter as zeros and only pass through row-wise
+        operations)."""
         p = self.dropout_p if self.training else 0.0
         seeds = seeds or _SeedStream(p > 0)
         inference = p == 0.0 and not torch.is_grad_enabled()      # sampling / validation
         newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
                                               edge_norm=(self.normE1, self.eps) if inference else None,
-                                              tile_map=tile_map if inference else None)
+                                              tile_map=tile_map if inference else None,
+                                              order=order if inference else None)
 
         def norm(ln, x, r):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
@@ -156,7 +161,7 @@ class XEyTransformerLayer(nn.Module):
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
         if inference:                                     # the edge feed-forward block in one pass
             E = ops.ffn_ln_inference(E, self.linE1.weight, self.linE1.bias, self.linE2.weight, self.linE2.bias,
-                                     self.normE2.weight, self.normE2.bias, self.eps, tile_map=tile_map)
+                                     self.normE2.weight, self.normE2.bias, self.eps, tile_map=tile_map, order=order)
         else:
             E = ff_block(self.normE2, self.linE1, self.linE2, E)
         y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y)
@@ -185,6 +190,20 @@ class GraphTransformer(nn.Module):
         self.mlp_out_E = nn.Sequential(nn.Linear(h["de"], hm["E"]), relu(), nn.Linear(hm["E"], output_dims["E"]))
         self.mlp_out_y = nn.Sequential(nn.Linear(h["dy"], hm["y"]), relu(), nn.Linear(hm["y"], output_dims["y"]))
 
+    def _padding_shortcuts(self, node_mask):
+        """(tile map, row order) of a node mask.  The tile map is cheap and built on first sight; a mask that comes back
+        (reverse diffusion passes the same mask tensor 500 times) also gets the packed row order, which costs a sort.
+        The entry keeps a reference to the mask tensor, so its address cannot be handed to another tensor, and the
+        version counter catches in-place changes."""
+        hit = self.__dict__.get("_pad_cache")
+        if hit is not None and hit["mask"] is node_mask and hit["version"] == node_mask._version:
+            if hit["order"] is None and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
+                hit["order"] = ops.edge_row_order(node_mask)
+            return (None, hit["order"]) if hit["order"] is not None else (hit["tile_map"], None)
+        hit = {"mask": node_mask, "version": node_mask._version, "tile_map": ops.edge_tile_map(node_mask), "order": None}
+        self.__dict__["_pad_cache"] = hit
+        return hit["tile_map"], None
+
     def forward(self, X, E, y, node_mask):
         n = X.shape[1]
         X, E, y = X.float(), E.float(), y.float()
@@ -197,12 +216,12 @@ class GraphTransformer(nn.Module):
         hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
         hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
         hy = mlp(self.mlp_in_y, y, True)
-        # ragged batch without gradients: padding tiles of the edge tensor are skipped by the fused inference kernels
-        tile_map = None
+        # ragged batch without gradients: the fused inference kernels skip the padding rows of the edge tensor
+        tile_map = order = None
         if not torch.is_grad_enabled() and not self.training:
-            tile_map = ops.edge_tile_map(node_mask)
+            tile_map, order = self._padding_shortcuts(node_mask)
         for layer in self.tf_layers:
-            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map)
+            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order)
         oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
         oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
         oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]

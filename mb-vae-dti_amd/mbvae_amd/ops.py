@@ -375,6 +375,34 @@ def edge_tile_map(node_mask):
     return pair.view(-1, 32).any(1).to(torch.uint8)
 
 
+class EdgeRowOrder:
+    """Packed order of the bs*n*n pair rows of a ragged batch for the fused inference kernels: `idx` (int32) lists the
+    valid rows (both nodes unmasked) in ascending order, padded to a multiple of 32 by repeating the last one, then
+    the padding rows, padded likewise; `nvalid` (int32 [1], on the device) is the number of valid rows.  Built
+    without a host synchronisation; the node mask must not change while the object is in use."""
+
+    def __init__(self, node_mask):
+        m = node_mask.bool()
+        pair = (m.unsqueeze(1) & m.unsqueeze(2)).reshape(-1)
+        M = pair.numel()
+        dev = pair.device
+        nv = pair.sum()
+        order = torch.argsort(~pair, stable=True)                      # valid rows first, each part ascending
+        nvt32 = (nv + 31) // 32 * 32
+        pos = torch.arange(M + 64, device=dev)
+        src = torch.where(pos < nvt32, torch.minimum(pos, (nv - 1).clamp(min=0)),
+                          torch.minimum(nv + pos - nvt32, torch.full_like(nv, M - 1)))
+        self.idx = order[src.clamp(min=0)].to(torch.int32).contiguous()
+        self.nvalid = nv.to(torch.int32).reshape(1).contiguous()
+        self.rows = M
+
+
+def edge_row_order(node_mask):
+    """EdgeRowOrder of a node mask, or None when the batch has fewer than 32 pair rows."""
+    bs, n = node_mask.shape
+    return EdgeRowOrder(node_mask) if bs * n * n >= 32 else None
+
+
 def zero_masked_pairs_(P, node_mask):
     """In place: P[b,i,j,:] = 0 where node i or j is masked.  The no-gradient form of edge_block leaves those rows
     unwritten; every consumer other than the fused e_out kernel (which skips them itself) calls this first."""
@@ -382,41 +410,53 @@ def zero_masked_pairs_(P, node_mask):
     return P.masked_fill_(~(m.unsqueeze(1) & m.unsqueeze(2)).unsqueeze(-1), 0.0)
 
 
-def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5, tile_map=None):
+def _order_args(order, tile_map, rows):
+    """(tile_ok, row_idx, nvalid) pointers of the optional padding shortcuts; a row order wins over a tile map."""
+    if order is not None:
+        if order.rows != rows:
+            raise ValueError("row order does not match the number of rows")
+        return 0, order.idx.data_ptr(), order.nvalid.data_ptr()
+    if tile_map is not None and tile_map.numel() != (rows + 31) // 32:
+        raise ValueError("tile_map does not match the number of rows")
+    return _ptr(tile_map), 0, 0
+
+
+def ffn_ln_inference(x, w1, b1, w2, b2, gamma, beta, eps=1e-5, tile_map=None, order=None):
     """LayerNorm(x + linear(relu(linear(x, w1, b1)), w2, b2)) * gamma + beta without gradients or dropout.
     One fused kernel where the widths allow (64 -> 128 -> 64), else the three separate kernels.
     tile_map (edge_tile_map): tiles marked 0 must consist of padding rows that all hold the same values; one of them
-    is evaluated and copied to the rest (same bits as evaluating each)."""
+    is evaluated and copied to the rest (same bits as evaluating each).  order (edge_row_order): the same guarantee
+    for the padding rows, and the valid rows are packed into whole tiles."""
     x = _f32c(x, "x")
     d, dff = x.shape[-1], w1.shape[0]
     rows = x.numel() // d
-    if tile_map is not None and tile_map.numel() != (rows + 31) // 32:
-        raise ValueError("tile_map does not match the number of rows")
+    tm, ri, nvp = _order_args(order, tile_map, rows)
     with torch.no_grad():
         out = torch.empty_like(x)
         if _lib.call("mbvae_edge_ffn_fwd", x.data_ptr(), _f32c(w1).data_ptr(), _ptr(b1), _f32c(w2).data_ptr(), _ptr(b2),
-                     _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), _ptr(tile_map), rows, d, dff,
+                     _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), tm, ri, nvp, rows, d, dff,
                      float(eps), _stream(), allow_unsupported=True):
             return out
         return ln_residual(x, linear(linear(x, w1, b1, act=1), w2, b2), gamma, beta, eps)
 
 
-def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5, tile_map=None):
+def edge_out_ln_inference(P, w, b, E, node_mask, n_nodes, gamma, beta, eps=1e-5, tile_map=None, order=None,
+                          uniform_padding=False):
     """LayerNorm(E + edge_mask * linear(P, w, b)) * gamma + beta without gradients or dropout: one fused kernel
     where the widths allow (256 -> 64), else the projection and the residual LayerNorm kernels.
-    P is only read on valid pairs (it may be uninitialised elsewhere); tile_map (edge_tile_map) lets whole padding
-    tiles go unfetched."""
+    P is only read on valid pairs (it may be uninitialised elsewhere); tile_map (edge_tile_map) or order
+    (edge_row_order) let whole padding tiles go unfetched; uniform_padding: every padding row of E holds the same
+    values, so one is normalised and copied to the rest."""
     P, E = _f32c(P, "P"), _f32c(E, "E")
     dx, de = P.shape[-1], E.shape[-1]
     rows = E.numel() // de
-    if tile_map is not None and tile_map.numel() != (rows + 31) // 32:
-        raise ValueError("tile_map does not match the number of rows")
+    tm, ri, nvp = _order_args(order, tile_map, rows)
     with torch.no_grad():
         out = torch.empty_like(E)
         m8 = _mask_u8(node_mask)
         if _lib.call("mbvae_edge_out_ln_fwd", P.data_ptr(), _f32c(w).data_ptr(), _ptr(b), E.data_ptr(), m8.data_ptr(),
-                     n_nodes, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), _ptr(tile_map), rows, dx,
-                     de, float(eps), _stream(), allow_unsupported=True):
+                     n_nodes, _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(), out.data_ptr(), tm, ri, nvp,
+                     int(bool(uniform_padding)), rows, dx, de, float(eps), _stream(), allow_unsupported=True):
             return out
         P = zero_masked_pairs_(P.view(-1, n_nodes, n_nodes, dx), node_mask).view_as(P)
         return ln_residual(E, linear(P, w, b, mask=node_mask, mask_mode=MASK_EDGE, n_nodes=n_nodes), gamma, beta, eps)

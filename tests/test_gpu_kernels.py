@@ -793,6 +793,18 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
         full = ops.ffn_ln_inference(xp, *dv[1:], 1e-5)
         skip = ops.ffn_ln_inference(xp, *dv[1:], 1e-5, tile_map=tm.cuda())
         assert torch.equal(full, skip), "padding-tile shortcut changed the result"
+        # packed row order: the valid tiles' rows first, then the (uniform) padding rows
+        class _Ord:
+            pass
+        rowflag = tm.repeat_interleave(32)[:rows].bool()
+        valid_rows, pad_rows = rowflag.nonzero().flatten(), (~rowflag).nonzero().flatten()
+        nv = valid_rows.numel()
+        head = torch.cat((valid_rows, valid_rows[-1:].repeat(-nv % 32)))
+        tail = torch.cat((pad_rows, pad_rows[-1:].repeat(-pad_rows.numel() % 32 + 64)))
+        o = _Ord(); o.rows = rows
+        o.idx = torch.cat((head, tail)).to(torch.int32).cuda(); o.nvalid = torch.tensor([nv], dtype=torch.int32).cuda()
+        packed = ops.ffn_ln_inference(xp, *dv[1:], 1e-5, order=o)
+        assert torch.equal(full, packed), "packed row order changed the result"
         skip0 = ops.ffn_ln_inference(xp[:64].contiguous().fill_(0.25), *dv[1:], 1e-5, tile_map=torch.zeros(2, dtype=torch.uint8).cuda())
         assert torch.equal(skip0, ops.ffn_ln_inference(torch.full((64, 64), 0.25).cuda(), *dv[1:], 1e-5))
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
@@ -827,6 +839,18 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
     assert int(tm.sum()) == int(flat.view(-1, 32).any(1).sum())
     got2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:], tile_map=tm)
     assert torch.equal(got2, got), "masked pairs of P leaked into the result"
+    if bs * n * n >= 32:
+        order = ops.edge_row_order(mask.cuda())
+        assert int(order.nvalid) == int(em.sum()) and order.idx.numel() >= bs * n * n + 64
+        got3 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:], order=order)
+        assert torch.equal(got3, got), "packed row order changed the result"
+        # uniform padding rows of E: one is normalised per wave, the others receive a copy
+        Eu = torch.where(em.bool(), E, E[0, 0, 0].expand_as(E)).contiguous()
+        au = (args[0], args[1], args[2], Eu.cuda()) + args[4:]
+        base = ops.edge_out_ln_inference(*au)
+        for kw in (dict(tile_map=tm), dict(order=order)):
+            gu = ops.edge_out_ln_inference(Pn.cuda(), *au[1:], uniform_padding=True, **kw)
+            assert torch.equal(gu, base), f"uniform-padding shortcut changed the result ({list(kw)})"
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
     sep = ops.edge_out_ln_inference(*args)
     sep2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:])
@@ -859,11 +883,20 @@ def test_denoiser_inference_padding_shortcuts_are_exact():
         real = O.edge_tile_map
         try:
             O.edge_tile_map = lambda m: None
+            net.__dict__.pop("_pad_cache")           # first sight of the mask again, and no tile map this time
             b = net(Xin, E0, yin, mask)
         finally:
             O.edge_tile_map = real
+            net.__dict__.pop("_pad_cache")
     assert real(mask) is not None and int(real(mask).sum()) < real(mask).numel()
     assert torch.equal(a.X, b.X) and torch.equal(a.E, b.E) and torch.equal(a.y, b.y)
+    with torch.no_grad():                            # second sight of the same mask tensor: packed row order
+        a1 = net(Xin, E0, yin, mask)
+        assert net._pad_cache["order"] is None and net._pad_cache["tile_map"] is not None
+        a2 = net(Xin, E0, yin, mask)
+    assert torch.equal(a.E, a1.E)
+    assert net._pad_cache["order"] is not None
+    assert torch.equal(a.X, a2.X) and torch.equal(a.E, a2.E) and torch.equal(a.y, a2.y)
     c = net(Xin, E0, yin, mask)                      # gradients enabled: training-form kernels
     assert_close(a.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(a.E, c.E.detach(), rtol=2e-5, what="E")
     assert_close(a.y, c.y.detach(), rtol=2e-5, what="y")
