@@ -642,6 +642,7 @@ class FullDTIModel(_Base):
         X, E = zT.X, zT.E
         ones = torch.ones((bs, 1), dtype=self.model_dtype, device=dev)
         steps = list(reversed(range(self.T)))
+        self.drug_decoder.prepare_padding_shortcuts(node_mask)     # the same mask for all T steps (and before any capture)
         if use_graph and len(steps) > 2:
             emb = drug_embeddings.contiguous()
             # the first step runs eagerly: it also creates every lazily built buffer (workspace, cached constants)

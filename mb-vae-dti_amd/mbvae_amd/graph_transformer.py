@@ -204,6 +204,13 @@ class GraphTransformer(nn.Module):
         self.__dict__["_pad_cache"] = hit
         return hit["tile_map"], None
 
+    def prepare_padding_shortcuts(self, node_mask):
+        """Builds the packed row order of `node_mask` right away (callers that know the same mask tensor is about to be
+        used many times, e.g. the reverse-diffusion loop; must run outside HIP graph capture)."""
+        self.__dict__["_pad_cache"] = {"mask": node_mask, "version": node_mask._version,
+                                       "tile_map": ops.edge_tile_map(node_mask), "order": None}
+        return self._padding_shortcuts(node_mask)
+
     def forward(self, X, E, y, node_mask):
         n = X.shape[1]
         X, E, y = X.float(), E.float(), y.float()
