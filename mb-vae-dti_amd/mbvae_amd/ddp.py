@@ -28,6 +28,7 @@ class BucketedGradSync:
         if cur:
             self._close(cur)
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._handles = []
         for p in self.params:
             self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
@@ -45,17 +46,29 @@ class BucketedGradSync:
     def _hook(self, p):
         b = self._bucket_of[p]
         self._ready[b] += 1
-        if self._ready[b] == len(self.buckets[b][1]) and self.world > 1:
+        if self._ready[b] == len(self.buckets[b][1]):
+            self._launch(b)
+
+    def _launch(self, b):
+        self._launched[b] = True
+        if self.world > 1:
             flat = self.buckets[b][0]
             self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
 
     def finish(self):
-        """Wait for the outstanding all-reduces and turn sums into means.  Call after backward()."""
+        """Wait for the outstanding all-reduces and turn sums into means.  Call after backward().  A bucket holding a
+        parameter that received no gradient in this step (e.g. the global-feature output head when the loss only uses
+        the node and edge logits) never fills up during backward: it is reduced here, with zeros for that parameter,
+        so every rank still ends the step with identical gradients."""
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
         for work, flat in self._pending:
             work.wait()
             flat.div_(self.world)
         self._pending.clear()
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
     def zero_grad(self):
         """Zero the flat buckets in place (gradients stay views: never set them to None)."""

@@ -97,8 +97,20 @@ def _ddp_worker(rank, world, port, out):
         grads = torch.cat([p.grad.reshape(-1).clone() for p in net.parameters()])
         if step == 0:
             sync.zero_grad()
+    # a parameter that takes no part in the loss (the denoiser's global-feature output head in the graph-only loss):
+    # its bucket never fills during backward and must still be reduced by finish()
+    torch.manual_seed(1)
+    used, unused = torch.nn.Linear(16, 4), torch.nn.Linear(16, 4)
+    sync2 = BucketedGradSync(list(used.parameters()) + list(unused.parameters()), bucket_bytes=1 << 20)   # ONE bucket
+    assert len(sync2.buckets) == 1
+    for step in range(2):
+        used(data[rank] * (step + 1)).pow(2).mean().backward()
+        sync2.finish()
+        g2 = torch.cat([p.grad.reshape(-1).clone() for p in used.parameters()])
+        assert all(float(p.grad.abs().max()) == 0.0 for p in unused.parameters())
+        sync2.zero_grad()
     if rank == 0:
-        torch.save(grads, out)
+        torch.save({"grads": grads, "partial": g2}, out)
     dist.destroy_process_group()
 
 
@@ -106,7 +118,8 @@ def test_bucketed_grad_sync_gloo_world2(tmp_path):
     out = str(tmp_path / "g.pt")
     port = _free_port()
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
-    got = torch.load(out, weights_only=True)
+    saved = torch.load(out, weights_only=True)
+    got = saved["grads"]
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
     g = torch.Generator().manual_seed(100)
@@ -118,6 +131,15 @@ def test_bucketed_grad_sync_gloo_world2(tmp_path):
         v = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         tot = v if tot is None else tot + v
     assert torch.allclose(got, tot / 2, rtol=1e-6, atol=1e-7)
+    torch.manual_seed(1)
+    used = torch.nn.Linear(16, 4)
+    tot = None
+    for r in range(2):
+        used.zero_grad()
+        used(data[r] * 2).pow(2).mean().backward()
+        v = torch.cat([p.grad.reshape(-1) for p in used.parameters()])
+        tot = v if tot is None else tot + v
+    assert torch.allclose(saved["partial"], tot / 2, rtol=1e-6, atol=1e-7), "bucket with an unused parameter was not reduced"
 
 
 class _FakeSampler(torch.nn.Module):
