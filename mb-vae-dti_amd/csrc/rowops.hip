@@ -223,7 +223,7 @@ static int ln_dispatch(bool fwd, int64_t D, const float* x, const float* r, cons
 
 // ------------------------------------------------------------------------------------------------
 // Pooling: x [bs, L, D] -> stats [bs, 4D] = mean | min | max | unbiased std over L, arg [bs, 2, D] (int32)
-// One 512-thread block per (graph, 256-feature chunk); lane owns 4 features, row groups stride over L.
+// One 512- or 1024-thread block per (graph, 256-feature chunk); lane owns 4 features, row groups stride over L.
 // Mean/variance use Welford updates per thread and Chan's pairwise merge across threads (stable in fp32).
 struct Moments { float n, mean, m2; };
 __device__ __forceinline__ void mom_add(Moments& a, float x) {
@@ -235,28 +235,39 @@ __device__ __forceinline__ void mom_merge(Moments& a, const Moments& b) {
   a.mean += d * (b.n / n); a.m2 += b.m2 + d * d * (a.n * b.n / n); a.n = n;
 }
 
-__global__ __launch_bounds__(512) void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
-                                                        int* __restrict__ arg, int L, int D) {
+template <int NT>
+__global__ __launch_bounds__(NT) void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       int* __restrict__ arg, int L, int D) {
   extern __shared__ float sm[];
   const int lpr = min(64, D / 4);                 // lanes per row (power of two)
-  const int groups = 512 / lpr;
+  const int groups = NT / lpr;
   const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
   const int b = blockIdx.y, c = blockIdx.x * 256 + sub * 4;
   const bool active = c < D;
   Moments mo[4]; float mn[4], mx[4]; int amn[4], amx[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { mo[q] = {0.f, 0.f, 0.f}; mn[q] = INFINITY; mx[q] = -INFINITY; amn[q] = 0x7fffffff; amx[q] = 0x7fffffff; }
-  if (active)
+  if (active) {
+    // Welford update with the row count and its reciprocal shared by the lane's four features (one division per
+    // row instead of four; the kernel is bound by this arithmetic, not by the 256 B it reads per row)
+    float cnt = 0.f;
     for (int l = grp; l < L; l += groups) {
       const float4 v = ld4(x + ((int64_t)b * L + l) * D + c);
       const float vv[4] = {v.x, v.y, v.z, v.w};
+      cnt += 1.f;
+      const float inv = 1.f / cnt;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        mom_add(mo[q], vv[q]);
+        const float d = vv[q] - mo[q].mean;
+        mo[q].mean += d * inv;
+        mo[q].m2 += d * (vv[q] - mo[q].mean);
         if (vv[q] < mn[q]) { mn[q] = vv[q]; amn[q] = l; }
         if (vv[q] > mx[q]) { mx[q] = vv[q]; amx[q] = l; }
       }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mo[q].n = cnt;
+  }
   // tree merge over row groups through LDS: layout [grp][sub][q][7]
   float* slot = sm + ((grp * lpr + sub) * 4) * 7;
 #pragma unroll
@@ -468,9 +479,18 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
   const int lpr = (int)(D / 4 < 64 ? D / 4 : 64);
   if (lpr & (lpr - 1)) return MBVAE_EUNSUPPORTED;     // D/4 must be a power of two (or D >= 256 and D % 256 == 0)
   if (D > 256 && (D % 256)) return MBVAE_EUNSUPPORTED;
-  const size_t smem = (size_t)512 * 4 * 7 * sizeof(float);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)bs), dim3(512), smem, stream, x, stats,
-                     (int*)arg, (int)L, (int)D);
+  // every thread walks its rows one after the other (each Welford step needs the previous mean), so long pair
+  // dimensions get 1024 threads per graph
+  const dim3 grid((unsigned)((D + 255) / 256), (unsigned)bs);
+  if (L >= 2048) {
+    const size_t smem = (size_t)1024 * 4 * 7 * sizeof(float);
+    if (hipFuncSetAttribute((const void*)pool_fwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return MBVAE_ELAUNCH;
+    hipLaunchKernelGGL(pool_fwd_kernel<1024>, grid, dim3(1024), smem, stream, x, stats, (int*)arg, (int)L, (int)D);
+  } else {
+    const size_t smem = (size_t)512 * 4 * 7 * sizeof(float);
+    hipLaunchKernelGGL(pool_fwd_kernel<512>, grid, dim3(512), smem, stream, x, stats, (int*)arg, (int)L, (int)D);
+  }
   return mbvae_launch_status();
 }
 
