@@ -118,7 +118,10 @@ int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const 
                           int64_t de, float eps, mbvae_stream_t stream);
 
 /* Packed row order, the alternative to tile_ok for both entry points above (pass tile_ok = NULL with it; M >= 32):
- * nvalid[0] = number of valid rows (a device int32, so that no host synchronisation is needed to build it);
+ * nvalid (two device int32, so that no host synchronisation is needed to build them): nvalid[0] = number of valid
+ * rows; nvalid[1] != 0 = evaluate and store only the FIRST padding tile (rows row_idx[32*ceil(nvalid[0]/32) ..+31],
+ * which carry the padding rows' common value from one kernel to the next) and leave every other padding row
+ * untouched -- for callers that read no other padding row (mbvae_pool_stats_pairs_fwd does not);
  * row_idx (int32, at least M + 64 entries) = the valid rows in ascending order, padded to a multiple of 32 by
  * repeating the last one, followed by the padding rows, padded likewise.  The kernels then form their 32-row tiles
  * from row_idx, so products are only spent on valid rows; the padding rows are treated as under tile_ok = 0.
@@ -142,6 +145,13 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
                          mbvae_stream_t stream);
 int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg, const float* dstats, float* dx,
                          int64_t bs, int64_t L, int64_t D, int accumulate, mbvae_stream_t stream);
+/* Forward-only form of the Etoy statistics (graph_transformer.py:57-65) for ragged batches in the packed row order of
+ * mbvae_edge_ffn_fwd: x [bs,n,n,D], mask [bs,n].  Only pairs of two unmasked nodes are read; the padding pairs, which
+ * all hold the row x[row_idx[32*ceil(nvalid/32)]] by the caller's guarantee (and need not be written anywhere else),
+ * enter as `count x that row`.  Same mathematics as mbvae_pool_stats_fwd over all n*n rows, different rounding.
+ * MBVAE_EUNSUPPORTED unless D == 64. */
+int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask, const int32_t* row_idx,
+                               const int32_t* nvalid, int64_t bs, int64_t n, int64_t D, mbvae_stream_t stream);
 
 /* ---- symmetrise + mask -----------------------------------------------------------------------------
  * Replaces graph_transformer.py:322,327 (input) and :338,341,343 (output):

@@ -260,14 +260,16 @@ struct EdgeFfnArgs {
 // to a multiple of 32 by repeating the last one, then the M - nvalid[0] padding rows, padded likewise.  Tile t of the
 // kernels is then rows row_idx[32t .. 32t+31] instead of rows 32t .. 32t+31: valid rows fill whole tiles (no products
 // are spent on padding rows that merely share a tile with valid ones) and the padding tiles follow.  Repeated
-// entries are evaluated and stored twice with the same values.
+// entries are evaluated and stored twice with the same values.  nvalid has two entries: the count and a flag.
 struct EfRowOrder {
   const int32_t* idx; int64_t nvt, ntiles;
   __device__ __forceinline__ EfRowOrder(const int32_t* row_idx, const int32_t* nvalid, int64_t M) : idx(row_idx) {
     if (row_idx) {
       const int64_t nv = nvalid[0];
       nvt = (nv + 31) / 32;
-      ntiles = nvt + (M - nv + 31) / 32;
+      // nvalid[1] != 0: only the FIRST padding tile is evaluated and stored (it carries the padding rows' common value
+      // from kernel to kernel); the caller reads no other padding row (mbvae_pool_stats_pairs_fwd does not).
+      ntiles = nvt + (nvalid[1] != 0 ? (int64_t)(nv < M) : (M - nv + 31) / 32);
     } else {
       nvt = 0;
       ntiles = (M + 31) / 32;       // the last tile may be partial: loads clamp, stores are guarded
@@ -357,7 +359,10 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     mode[S] = md;                                                                                      \
     srow[S] = nxt_row;                                                                                 \
     sinb[S] = ord.inb(wid + k * nw, r, a.M);                                                           \
+    /* the next tile's row index is requested BEFORE this tile's operands: the memory counter is in order, so the  \
+       wait for the index (next fetch) then leaves the operand loads issued after it in flight */      \
     nxt_row = ord.row(wid + min((int64_t)(q) + 1, mine - 1) * nw, r, a.M);                             \
+    asm volatile("" : : : "memory");                                                                   \
     const float* src = a.x + (int64_t)(md == 2 ? min(r, (int)a.M - 1) : srow[S]) * 64 + 32 * h;        \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
@@ -506,7 +511,10 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
     {                                                  /* step to the next group's tile */             \
       const int64_t q1 = min(qq + 1, total - 1);                                                       \
       cur_row = (q1 >> 2) != (qq >> 2) ? nxt_row : cur_row;                                            \
+      /* requested BEFORE this group's operands: the memory counter is in order, so the wait for the index (next     \
+         fetch) then leaves the operand loads issued after it in flight */                             \
       nxt_row = ord.row(wid + min((q1 >> 2) + 1, mine - 1) * nw, r, a.M);                              \
+      asm volatile("" : : : "memory");                                                                 \
     }                                                                                                  \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \

@@ -305,6 +305,93 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// Inference form of the pair pooling for ragged batches whose padding pair rows all hold ONE row of values (the
+// denoiser's edge tensor: see mbvae_edge_ffn_fwd): only the valid pairs (i, j) of a graph are read; the padding
+// rows enter as `count x the constant row`, merged with Chan's formula (exact arithmetic, different rounding than
+// walking over them).  The constant row is x[row_idx[32 * ceil(nvalid / 32)]], the first padding row of the packed
+// row order; the padding rows themselves need not have been written.  No arg-min / arg-max output (forward only).
+// One 1024-thread block per graph; D = 64.
+__global__ __launch_bounds__(1024) void pool_pairs_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                              const uint8_t* __restrict__ mask,
+                                                              const int32_t* __restrict__ row_idx,
+                                                              const int32_t* __restrict__ nvalid, int n, int64_t M) {
+  extern __shared__ float sm[];                    // [64 groups][16 lanes][4][5]
+  __shared__ uint8_t mk[1024];
+  constexpr int D = 64, LPR = 16, GROUPS = 64;
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int b = blockIdx.x, c = sub * 4;
+  for (int t = threadIdx.x; t < n; t += 1024) mk[t] = mask[(int64_t)b * n + t];
+  __syncthreads();
+  Moments mo[4]; float mn[4], mx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { mo[q] = {0.f, 0.f, 0.f}; mn[q] = INFINITY; mx[q] = -INFINITY; }
+  const int L = n * n;
+  float cnt = 0.f, skipped = 0.f;
+  int i = grp / n, j = grp % n;
+  for (int l = grp; l < L; l += GROUPS) {
+    if (mk[i] && mk[j]) {
+      const float4 v = ld4(x + ((int64_t)b * L + l) * D + c);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      cnt += 1.f;
+      const float inv = 1.f / cnt;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float d = vv[q] - mo[q].mean;
+        mo[q].mean += d * inv;
+        mo[q].m2 += d * (vv[q] - mo[q].mean);
+        mn[q] = fminf(mn[q], vv[q]); mx[q] = fmaxf(mx[q], vv[q]);
+      }
+    } else {
+      skipped += 1.f;
+    }
+    j += GROUPS;
+    while (j >= n) { j -= n; ++i; }
+  }
+  const int64_t nv = nvalid[0];
+  if (skipped > 0.f && nv < M) {
+    const float4 cv = ld4(x + (int64_t)row_idx[(nv + 31) / 32 * 32] * D + c);
+    const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mo[q].n = cnt;
+      const Moments pad = {skipped, cc[q], 0.f};
+      mom_merge(mo[q], pad);
+      mn[q] = fminf(mn[q], cc[q]); mx[q] = fmaxf(mx[q], cc[q]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mo[q].n = cnt;
+  }
+  float* slot = sm + ((grp * LPR + sub) * 4) * 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float* s = slot + q * 5;
+    s[0] = mo[q].n; s[1] = mo[q].mean; s[2] = mo[q].m2; s[3] = mn[q]; s[4] = mx[q];
+  }
+  for (int stride = GROUPS / 2; stride > 0; stride >>= 1) {
+    __syncthreads();
+    if (grp < stride) {
+      const float* o = sm + (((grp + stride) * LPR + sub) * 4) * 5;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* s = slot + q * 5; const float* t = o + q * 5;
+        Moments a = {s[0], s[1], s[2]}; const Moments bb = {t[0], t[1], t[2]};
+        mom_merge(a, bb); s[0] = a.n; s[1] = a.mean; s[2] = a.m2;
+        s[3] = fminf(s[3], t[3]); s[4] = fmaxf(s[4], t[4]);
+      }
+    }
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* s = slot + q * 5;
+      float* o = stats + (int64_t)b * 4 * D;
+      o[c + q] = s[1]; o[D + c + q] = s[3]; o[2 * D + c + q] = s[4];
+      o[3 * D + c + q] = sqrtf(s[2] / (s[0] - 1.f));
+    }
+  }
+}
+
 // dx[b,l,c] (+)= dmean/L + dstd*(x-mean)/((L-1)*std) [0 if std==0] + [l==argmin]*dmin + [l==argmax]*dmax
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                        const int* __restrict__ arg, const float* __restrict__ dstats,
@@ -491,6 +578,20 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
     const size_t smem = (size_t)512 * 4 * 7 * sizeof(float);
     hipLaunchKernelGGL(pool_fwd_kernel<512>, grid, dim3(512), smem, stream, x, stats, (int*)arg, (int)L, (int)D);
   }
+  return mbvae_launch_status();
+}
+
+// x [bs,n,n,64] -> stats [bs,256] as above, reading only the pairs whose two nodes are unmasked; see the kernel.
+int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask, const int32_t* row_idx,
+                               const int32_t* nvalid, int64_t bs, int64_t n, int64_t D, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!x || !stats || !mask || !row_idx || !nvalid || bs <= 0 || n <= 0) return MBVAE_EINVAL;
+  if (D != 64 || n > 1024 || bs > 0x7fffffff || bs * n * n > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const size_t smem = (size_t)1024 * 4 * 5 * sizeof(float);
+  if (hipFuncSetAttribute((const void*)pool_pairs_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return MBVAE_ELAUNCH;
+  hipLaunchKernelGGL(pool_pairs_fwd_kernel, dim3((unsigned)bs), dim3(1024), smem, stream, x, stats, mask, row_idx, nvalid,
+                     (int)n, bs * n * n);
   return mbvae_launch_status();
 }
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mbvae_ln_residual_bwd_workspace": [_L],
     "mbvae_ln_residual_bwd": [_P] * 10 + [_L, _L, _F, _U, _P, _L, _P],
     "mbvae_pool_stats_fwd": [_P, _P, _P, _L, _L, _L, _P],
+    "mbvae_pool_stats_pairs_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _P],
     "mbvae_pool_stats_bwd": [_P, _P, _P, _P, _P, _L, _L, _L, _I, _P],
     "mbvae_sym_mask": [_P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
     "mbvae_masked_ce_workspace": [],

@@ -96,7 +96,8 @@ class NodeEdgeBlock(nn.Module):
         yp = self._fused("y5", y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
-        P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head)
+        P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head,
+                                                 order=order if edge_norm is not None else None)
         if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
             ln, eps = edge_norm
             newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps,
@@ -188,6 +189,8 @@ class GraphTransformer(nn.Module):
                                 dim_ffE=h["dim_ffE"], dim_ffy=h["dim_ffy"]) for _ in range(n_layers)])
         self.mlp_out_X = nn.Sequential(nn.Linear(h["dx"], hm["X"]), relu(), nn.Linear(hm["X"], output_dims["X"]))
         self.mlp_out_E = nn.Sequential(nn.Linear(h["de"], hm["E"]), relu(), nn.Linear(hm["E"], output_dims["E"]))
+        # the widths the fused inference edge kernels (and with them the packed row order) are written for
+        self._fused_edge_widths = (h["dx"], h["de"], h["dim_ffE"]) == (256, 64, 128)
         self.mlp_out_y = nn.Sequential(nn.Linear(h["dy"], hm["y"]), relu(), nn.Linear(hm["y"], output_dims["y"]))
 
     def _padding_shortcuts(self, node_mask):
@@ -197,8 +200,8 @@ class GraphTransformer(nn.Module):
         version counter catches in-place changes."""
         hit = self.__dict__.get("_pad_cache")
         if hit is not None and hit["mask"] is node_mask and hit["version"] == node_mask._version:
-            if hit["order"] is None and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
-                hit["order"] = ops.edge_row_order(node_mask)
+            if hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
+                hit["order"] = ops.edge_row_order(node_mask, sparse=True)
             return (None, hit["order"]) if hit["order"] is not None else (hit["tile_map"], None)
         hit = {"mask": node_mask, "version": node_mask._version, "tile_map": ops.edge_tile_map(node_mask), "order": None}
         self.__dict__["_pad_cache"] = hit
@@ -229,6 +232,8 @@ class GraphTransformer(nn.Module):
             tile_map, order = self._padding_shortcuts(node_mask)
         for layer in self.tf_layers:
             hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order)
+        if order is not None and order.sparse and self.n_layers > 0:
+            ops.zero_masked_pairs_(hE, node_mask)    # the sparse order left most padding rows of hE unwritten
         oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
         oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
         oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]

@@ -269,7 +269,7 @@ class _EdgeBlock(torch.autograd.Function):
     kernel does not take run the two separate forward kernels; the backward is the same either way."""
 
     @staticmethod
-    def forward(ctx, E, w, b, QKV, ye_add, ye_mul, mask, n_head):
+    def forward(ctx, E, w, b, QKV, ye_add, ye_mul, mask, n_head, order=None):
         E, w, QKV, ye_add, ye_mul = (_f32c(t) for t in (E, w, QKV, ye_add, ye_mul))
         bs, n, dx3 = QKV.shape
         dx, de = dx3 // 3, E.shape[-1]
@@ -297,9 +297,13 @@ class _EdgeBlock(torch.autograd.Function):
             _lib.call("mbvae_edge_attn_fwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, N,
                       ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
                       bs, n, dx, scale, _stream())
-        stats = torch.empty((bs, 4 * de), dtype=torch.float32, device=dev)
-        arg = torch.empty((bs, 2, de), dtype=torch.int32, device=dev)
-        _lib.call("mbvae_pool_stats_fwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, n * n, de, _stream())
+        if order is not None and order.sparse and not need_grad:
+            stats = pool_stats_pairs(E, order)       # E's padding rows are not all written: pool the valid pairs
+            arg = None
+        else:
+            stats = torch.empty((bs, 4 * de), dtype=torch.float32, device=dev)
+            arg = torch.empty((bs, 2, de), dtype=torch.int32, device=dev)
+            _lib.call("mbvae_pool_stats_fwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, n * n, de, _stream())
         if need_grad:
             ctx.save_for_backward(E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse)
         ctx.cfg = (n, b is not None, scale)
@@ -312,14 +316,15 @@ class _EdgeBlock(torch.autograd.Function):
         dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV)
         dE, dw, db = _edge_input_grads(E, w, m8, stats, arg, n, has_bias, dE12, dstats, dres,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dE, dw, db, dQKV, dya, dym, None, None
+        return dE, dw, db, dQKV, dya, dym, None, None, None
 
 
-def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head):
+def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order=None):
     """(P, wV, pooling statistics of E, alias of E): edge_input followed by edge_attention, with the projection
     output kept out of memory whenever the fused forward kernel takes the shape.  Without gradients P is only
-    written for valid pairs (see zero_masked_pairs_)."""
-    return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head)
+    written for valid pairs (see zero_masked_pairs_).  order: a sparse EdgeRowOrder says that E's padding rows hold
+    one common row of which only the order's first padding tile is actually stored (see EdgeRowOrder)."""
+    return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order)
 
 
 # ------------------------------------------------------------------------------------------------ residual + LayerNorm
@@ -378,10 +383,13 @@ def edge_tile_map(node_mask):
 class EdgeRowOrder:
     """Packed order of the bs*n*n pair rows of a ragged batch for the fused inference kernels: `idx` (int32) lists the
     valid rows (both nodes unmasked) in ascending order, padded to a multiple of 32 by repeating the last one, then
-    the padding rows, padded likewise; `nvalid` (int32 [1], on the device) is the number of valid rows.  Built
-    without a host synchronisation; the node mask must not change while the object is in use."""
+    the padding rows, padded likewise; `nvalid` (int32 [2], on the device) holds the number of valid rows and the
+    `sparse` flag.  With sparse=True the kernels evaluate and store only the first padding tile (it carries the
+    padding rows' common value from kernel to kernel) and leave the other padding rows of their outputs unwritten:
+    the caller must then pool with pool_stats_pairs and call zero_masked_pairs_ before any other consumer.
+    Built without a host synchronisation; the node mask must not change while the object is in use."""
 
-    def __init__(self, node_mask):
+    def __init__(self, node_mask, sparse=False):
         m = node_mask.bool()
         pair = (m.unsqueeze(1) & m.unsqueeze(2)).reshape(-1)
         M = pair.numel()
@@ -393,14 +401,31 @@ class EdgeRowOrder:
         src = torch.where(pos < nvt32, torch.minimum(pos, (nv - 1).clamp(min=0)),
                           torch.minimum(nv + pos - nvt32, torch.full_like(nv, M - 1)))
         self.idx = order[src.clamp(min=0)].to(torch.int32).contiguous()
-        self.nvalid = nv.to(torch.int32).reshape(1).contiguous()
+        self.nvalid = torch.stack((nv, torch.full_like(nv, int(sparse)))).to(torch.int32).contiguous()
         self.rows = M
+        self.sparse = bool(sparse)
+        self.mask_u8 = _mask_u8(node_mask)
+        self.n = node_mask.shape[1]
 
 
-def edge_row_order(node_mask):
+def edge_row_order(node_mask, sparse=False):
     """EdgeRowOrder of a node mask, or None when the batch has fewer than 32 pair rows."""
     bs, n = node_mask.shape
-    return EdgeRowOrder(node_mask) if bs * n * n >= 32 else None
+    return EdgeRowOrder(node_mask, sparse) if bs * n * n >= 32 else None
+
+
+def pool_stats_pairs(E, order):
+    """[bs, 4*de] = mean | min | max | unbiased std of E [bs,n,n,de] over all n*n pairs, reading only the valid pairs:
+    the padding pairs all hold the row E[order's first padding row] (caller's guarantee) and enter analytically.
+    No gradients; raises for widths the kernel does not take (de != 64)."""
+    E = _f32c(E, "E")
+    bs, n, de = E.shape[0], E.shape[1], E.shape[-1]
+    stats = torch.empty((bs, 4 * de), dtype=torch.float32, device=E.device)
+    with torch.no_grad():
+        if not _lib.call("mbvae_pool_stats_pairs_fwd", E.data_ptr(), stats.data_ptr(), order.mask_u8.data_ptr(),
+                         order.idx.data_ptr(), order.nvalid.data_ptr(), bs, n, de, _stream(), allow_unsupported=True):
+            raise RuntimeError("pool_stats_pairs: unsupported width for a sparse row order")
+    return stats
 
 
 def zero_masked_pairs_(P, node_mask):

@@ -802,9 +802,21 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
         head = torch.cat((valid_rows, valid_rows[-1:].repeat(-nv % 32)))
         tail = torch.cat((pad_rows, pad_rows[-1:].repeat(-pad_rows.numel() % 32 + 64)))
         o = _Ord(); o.rows = rows
-        o.idx = torch.cat((head, tail)).to(torch.int32).cuda(); o.nvalid = torch.tensor([nv], dtype=torch.int32).cuda()
+        o.idx = torch.cat((head, tail)).to(torch.int32).cuda(); o.nvalid = torch.tensor([nv, 0], dtype=torch.int32).cuda()
         packed = ops.ffn_ln_inference(xp, *dv[1:], 1e-5, order=o)
         assert torch.equal(full, packed), "packed row order changed the result"
+        # sparse form: the valid rows and the first padding tile are written, nothing else is
+        o.nvalid = torch.tensor([nv, 1], dtype=torch.int32).cuda()
+        canvas = torch.full_like(full, 7.0)
+        import mbvae_amd._lib as L
+        assert L.call("mbvae_edge_ffn_fwd", xp.data_ptr(), *(t.data_ptr() for t in dv[1:5]), dv[5].data_ptr(), dv[6].data_ptr(),
+                      canvas.data_ptr(), 0, o.idx.data_ptr(), o.nvalid.data_ptr(), rows, 64, 128, 1e-5,
+                      torch.cuda.current_stream().cuda_stream)
+        written = torch.zeros(rows, dtype=torch.bool)
+        written[valid_rows] = True
+        written[tail[:32].long()] = True
+        assert torch.equal(canvas[written.cuda()], full[written.cuda()])
+        assert bool((canvas[~written.cuda()] == 7.0).all()), "the sparse order wrote padding rows beyond its first padding tile"
         skip0 = ops.ffn_ln_inference(xp[:64].contiguous().fill_(0.25), *dv[1:], 1e-5, tile_map=torch.zeros(2, dtype=torch.uint8).cuda())
         assert torch.equal(skip0, ops.ffn_ln_inference(torch.full((64, 64), 0.25).cuda(), *dv[1:], 1e-5))
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
@@ -841,7 +853,7 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
     assert torch.equal(got2, got), "masked pairs of P leaked into the result"
     if bs * n * n >= 32:
         order = ops.edge_row_order(mask.cuda())
-        assert int(order.nvalid) == int(em.sum()) and order.idx.numel() >= bs * n * n + 64
+        assert int(order.nvalid[0]) == int(em.sum()) and order.idx.numel() >= bs * n * n + 64
         got3 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:], order=order)
         assert torch.equal(got3, got), "packed row order changed the result"
         # uniform padding rows of E: one is normalised per wave, the others receive a copy
@@ -851,6 +863,18 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
         for kw in (dict(tile_map=tm), dict(order=order)):
             gu = ops.edge_out_ln_inference(Pn.cuda(), *au[1:], uniform_padding=True, **kw)
             assert torch.equal(gu, base), f"uniform-padding shortcut changed the result ({list(kw)})"
+        # sparse order: valid rows + the first padding tile only; the pair pooling fills in the rest analytically
+        sp = ops.edge_row_order(mask.cuda(), sparse=True)
+        gs = ops.edge_out_ln_inference(Pn.cuda(), *au[1:], uniform_padding=True, order=sp)
+        nv = int(sp.nvalid[0])
+        written = em.reshape(-1).bool().clone()
+        if nv < written.numel():
+            written[sp.idx[(nv + 31) // 32 * 32:(nv + 31) // 32 * 32 + 32].long().cpu()] = True
+        assert torch.equal(gs.reshape(-1, 64)[written.cuda()], base.reshape(-1, 64)[written.cuda()])
+        if bs * n * n >= 64 and n <= 64:
+            dense = ops.pool_stats(base)
+            ragged = ops.pool_stats_pairs(gs, sp)
+            assert_close(ragged, dense, rtol=1e-5, what="pair pooling with analytic padding")
     monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
     sep = ops.edge_out_ln_inference(*args)
     sep2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:])
@@ -895,8 +919,10 @@ def test_denoiser_inference_padding_shortcuts_are_exact():
         assert net._pad_cache["order"] is None and net._pad_cache["tile_map"] is not None
         a2 = net(Xin, E0, yin, mask)
     assert torch.equal(a.E, a1.E)
-    assert net._pad_cache["order"] is not None
-    assert torch.equal(a.X, a2.X) and torch.equal(a.E, a2.E) and torch.equal(a.y, a2.y)
+    assert net._pad_cache["order"] is not None and net._pad_cache["order"].sparse
+    # the sparse order pools the padding pairs analytically: same mathematics, different rounding
+    assert_close(a2.X, a.X, rtol=2e-5, what="X (sparse order)"); assert_close(a2.E, a.E, rtol=2e-5, what="E (sparse order)")
+    assert_close(a2.y, a.y, rtol=2e-5, what="y (sparse order)")
     c = net(Xin, E0, yin, mask)                      # gradients enabled: training-form kernels
     assert_close(a.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(a.E, c.E.detach(), rtol=2e-5, what="E")
     assert_close(a.y, c.y.detach(), rtol=2e-5, what="y")
