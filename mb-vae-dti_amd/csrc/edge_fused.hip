@@ -376,6 +376,16 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     int oz;                                                                                            \
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));                                                        \
     const int h4 = 4 * h + oz;                                                                         \
+    /* the residual operand (this lane's 32 output columns of its row; cache hits, the row was just read) is      \
+       requested before the products: asked for in the epilogue it costs a full memory latency per tile AND, the  \
+       memory counter being in order, drags the wait for the next tile's prefetch along */            \
+    float4 xres[8];                                                                                    \
+    {                                                                                                  \
+      const float* xrow = a.x + (int64_t)srow[S] * 64 + 4 * h;                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) xres[4 * u + gq] = ef_ld4(xrow + 32 * u + 8 * gq); \
+      asm volatile("" : : : "memory");                                                                 \
+    }                                                                                                  \
     /* hidden layer, transposed: rows = hidden units (4 tiles of 32), columns = the tile's 32 rows */  \
     f32x16 hh[4];                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
@@ -404,12 +414,11 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     }                                                                                                  \
     /* residual + LayerNorm: this lane has columns 32u + 8g + 4h + (0..3) of row `tile*32 + r` */      \
     const bool inb = sinb[S];                                                                          \
-    const float* xrow = a.x + (int64_t)srow[S] * 64 + 4 * h;                                           \
     float z[2][16];                                                                                    \
     float sum = 0.f;                                                                                   \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
-        const float4 xr = ef_ld4(xrow + 32 * u + 8 * gq);                                              \
+        const float4 xr = xres[4 * u + gq];                                                            \
         z[u][4 * gq + 0] = yy[u][4 * gq + 0] + xr.x; z[u][4 * gq + 1] = yy[u][4 * gq + 1] + xr.y;      \
         z[u][4 * gq + 2] = yy[u][4 * gq + 2] + xr.z; z[u][4 * gq + 3] = yy[u][4 * gq + 3] + xr.w;      \
         sum += (z[u][4 * gq] + z[u][4 * gq + 1]) + (z[u][4 * gq + 2] + z[u][4 * gq + 3]);              \
@@ -519,11 +528,21 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
     _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                      \
     asm volatile("" : : : "memory");                                                                   \
   }
-#define EO_GROUP(q, S)                                                                                \
+  float4 xres[8];                                   // residual operand of the tile being finished
+  unsigned mka = 1u, mkb = 1u;                      // its row's two mask bytes
+#define EO_GROUP(q, S, GI)                                                                            \
   if ((q) < total && mode[S] == 2) {                                                                  \
-    if (((q) & 3) == 3) ef_store_row_tile(a.out, my_cst, srow[S], sinb[S], lane);                      \
+    if (GI == 3) ef_store_row_tile(a.out, my_cst, srow[S], sinb[S], lane);                             \
   } else if ((q) < total) {                                                                           \
-    const int gi = (int)((q) & 3);                                                                     \
+    constexpr int gi = GI;                                                                             \
+    if (GI == 3) {                                                                                     \
+      /* residual row and mask bytes are requested before the last group's products (see the feed-forward kernel) */ \
+      const float* xrow = a.E + (int64_t)srow[S] * 64 + 4 * h;                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) xres[4 * u + gq] = ef_ld4(xrow + 32 * u + 8 * gq); \
+      mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, srow[S], a.n, a.P, mka, mkb); \
+      asm volatile("" : : : "memory");                                                                 \
+    }                                                                                                  \
     int oz;          /* opaque zero: keeps the loop-invariant LDS values from being hoisted into registers */ \
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));                                                        \
     const int h4 = 4 * h + oz;                                                                         \
@@ -545,15 +564,12 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
     if (gi == 3) {                                   /* row finished: mask, residual, LayerNorm */     \
       const bool inb = sinb[S];                                                                        \
       const int64_t row = srow[S];                                                                     \
-      unsigned ma, mb;                                                                                 \
-      mbvae_row_mask_bytes(a.mask, a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, row, a.n, a.P, ma, mb);  \
-      const bool keep = mode[S] == 0 && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, ma, mb); \
-      const float* xrow = a.E + row * 64 + 4 * h;                                                      \
+      const bool keep = mode[S] == 0 && mbvae_mask_keep(a.mask ? MBVAE_MASK_EDGE : MBVAE_MASK_NONE, mka, mkb); \
       float z[2][16];                                                                                  \
       float sum = 0.f;                                                                                 \
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                             \
-          const float4 xr = ef_ld4(xrow + 32 * u + 8 * gq);                                            \
+          const float4 xr = xres[4 * u + gq];                                                          \
           /* a select, not a product: P of a masked pair may hold anything (the attention kernel skips it) */ \
           z[u][4 * gq + 0] = (keep ? yy[u][4 * gq + 0] : 0.f) + xr.x; z[u][4 * gq + 1] = (keep ? yy[u][4 * gq + 1] : 0.f) + xr.y; \
           z[u][4 * gq + 2] = (keep ? yy[u][4 * gq + 2] : 0.f) + xr.z; z[u][4 * gq + 3] = (keep ? yy[u][4 * gq + 3] : 0.f) + xr.w; \
@@ -581,11 +597,15 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
     }                                                                                                  \
   }
   EO_FETCH(0, 0)
-  for (int64_t q = 0; q < total; q += 2) {
+  for (int64_t q = 0; q < total; q += 4) {          // total is a multiple of 4: the group index is a constant per line
     EO_FETCH(q + 1, 1)
-    EO_GROUP(q, 0)
+    EO_GROUP(q, 0, 0)
     EO_FETCH(q + 2, 0)
-    EO_GROUP(q + 1, 1)
+    EO_GROUP(q + 1, 1, 1)
+    EO_FETCH(q + 3, 1)
+    EO_GROUP(q + 2, 0, 2)
+    EO_FETCH(q + 4, 0)
+    EO_GROUP(q + 3, 1, 3)
   }
 #undef EO_FETCH
 #undef EO_GROUP
