@@ -82,11 +82,14 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
  * ends): the workgroups draw their (graph, block of query rows) tasks from it first come first served, which evens
  * out ragged batches; with NULL the tasks are dealt round robin.  Calls that overlap on one device need separate
  * counters.  The results do not depend on the order.
+ * node_off (NULL, or int32 [bs+1]; inference form only): packed node rows.  Q, K, V, wV and lse then hold only the
+ * valid nodes, graph b's nodes 0 .. nb-1 at rows node_off[b] .. node_off[b+1]-1 (the mask must keep exactly the first
+ * nb nodes of graph b); rows of masked nodes do not exist and are neither read nor written.  E and P stay dense.
  * MBVAE_EUNSUPPORTED unless de == 64, dx == 256 and n <= 64: callers then use the two separate entry points. */
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
-                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, int64_t bs, int64_t n,
-                         int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
+                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
+                         int64_t bs, int64_t n, int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
 
 /* ---- edge feed-forward block, inference form ----------------------------------------------------------
  * Replaces `normE2(E + linE2(relu(linE1(E))))` of XEyTransformerLayer.forward (graph_transformer.py:139-142) when
@@ -150,6 +153,11 @@ int mbvae_pool_stats_bwd(const float* x, const float* stats, const int32_t* arg,
  * all hold the row x[row_idx[32*ceil(nvalid/32)]] by the caller's guarantee (and need not be written anywhere else),
  * enter as `count x that row`.  Same mathematics as mbvae_pool_stats_fwd over all n*n rows, different rounding.
  * MBVAE_EUNSUPPORTED unless D == 64. */
+/* Forward-only Xtoy statistics (graph_transformer.py:40-46) over packed node rows: x [rows,D] holds graph b's valid
+ * nodes at rows node_off[b] .. node_off[b+1]-1; its n - nb padding nodes all hold the row x[pad_row] and enter as
+ * `count x that row`.  stats [bs,4D].  D % 256 == 0 or D in {64, 128}. */
+int mbvae_pool_stats_nodes_fwd(const float* x, float* stats, const int32_t* node_off, int64_t pad_row, int64_t bs,
+                               int64_t n, int64_t D, mbvae_stream_t stream);
 int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask, const int32_t* row_idx,
                                const int32_t* nvalid, int64_t bs, int64_t n, int64_t D, mbvae_stream_t stream);
 

@@ -25,6 +25,7 @@ struct EdgeFusedArgs {
   float* P; float* wV; float* lse; float* E12;
   int bs, n; float scale; int ichunks;
   int* queue;      // optional work counter (zeroed before the launch): workgroups take tasks in order as they finish
+  const int* node_off;   // optional [bs+1]: Q, K, V, wV, lse hold only the valid nodes, graph b's at rows node_off[b]..
 };
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -79,11 +80,16 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
     const int b = task / a.ichunks, ic = task - b * a.ichunks;
     const int i0 = ic * ipc, i1 = min(n, i0 + ipc);
     const int64_t node = (int64_t)b * n;
+    // packed node rows (inference, masks that keep a prefix of each graph's nodes): node (b, i) is row pnode + i for
+    // i < nb; the rows of masked keys are never used, any readable row stands in for them
+    const int64_t pnode = a.node_off ? a.node_off[b] : node;
+    const int nb = a.node_off ? a.node_off[b + 1] - a.node_off[b] : n;
     __syncthreads();                               // every wave is done with the previous graph's K, V rows
     for (int e = tid; e < n * 64; e += 512) {
       const int j = e >> 6, c4 = (e & 63) * 4;
-      *reinterpret_cast<float4*>(Ks + j * 256 + c4) = ef_ld4(a.K + (node + j) * ldq + c4);
-      *reinterpret_cast<float4*>(Vs + j * 256 + c4) = ef_ld4(a.V + (node + j) * ldq + c4);
+      const int64_t src = pnode + (j < nb ? j : 0);
+      *reinterpret_cast<float4*>(Ks + j * 256 + c4) = ef_ld4(a.K + src * ldq + c4);
+      *reinterpret_cast<float4*>(Vs + j * 256 + c4) = ef_ld4(a.V + src * ldq + c4);
     }
     const unsigned long long kmask = __ballot(lane < n && a.mask[node + min(lane, n - 1)] != 0);   // bit j: key j valid
     const float ya = a.ye_add[(int64_t)b * 256 + c], ym1 = a.ye_mul[(int64_t)b * 256 + c] + 1.f;
@@ -95,9 +101,10 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
     if (!WRITE_E12) {
       const int top = kmask ? 64 - __builtin_clzll(kmask) : 0;   // 1 + index of the last valid node
       RTq = top > 32 ? 2 : 1;
-      iend = min(i1, top);
-      for (int i = max(i0, top); i < i1; ++i)
-        if (h == 0) { a.wV[(node + i) * 256 + c] = 0.f; a.lse[(node + i) * 256 + c] = INFINITY; }
+      iend = min(i1, min(top, nb));
+      if (!a.node_off)
+        for (int i = max(i0, top); i < i1; ++i)
+          if (h == 0) { a.wV[(node + i) * 256 + c] = 0.f; a.lse[(node + i) * 256 + c] = INFINITY; }
     }
     const int T = (iend - i0) * RTq;               // tiles of this task
     if (T <= 0) continue;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const int j = min(32 * mt + r, n - 1);                                                           \
       const float* src = a.E + ((qrow * n + j) * 64 + 32 * h);                                         \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                    \
-      qv[S] = a.Q[qrow * ldq + c];                                                                     \
+      qv[S] = a.Q[(pnode + i0 + ii) * ldq + c];                                                        \
       asm volatile("" : : : "memory");       /* issue the loads here, do not sink them to their use */ \
     }
 #define EF_ST(ptr_rsrc, val, voff, soff) \
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           o = (av_run * ea + ao * eb) / lt;                                                            \
           s = M + __logf(lt);                                                                          \
         }                                                                                              \
-        if (h == 0) { a.wV[(node + i) * 256 + c] = o; a.lse[(node + i) * 256 + c] = s; }               \
+        if (h == 0) { a.wV[(pnode + i) * 256 + c] = o; a.lse[(pnode + i) * 256 + c] = s; }             \
       }                                                                                                \
     }
 
@@ -628,11 +635,13 @@ extern "C" {
 // when E12 is not null, the projection output E1|E2 [bs,n,n,2dx] (what the backward kernels read).
 // work_counter: NULL, or one int32 of device memory the call may overwrite (it is zeroed on `stream` first): the
 // workgroups then draw (graph, query-row block) tasks from it in order instead of a fixed round robin.
+// node_off: NULL, or int32 [bs+1] (inference form only, masks that keep a prefix of every graph's nodes): Q, K, V, wV
+// and lse then hold the valid nodes only, graph b's nodes 0..nb-1 at rows node_off[b] .. node_off[b+1]-1.
 // MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
-                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, int64_t bs, int64_t n,
-                         int64_t de, int64_t dx, float scale, hipStream_t stream) {
+                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
+                         int64_t bs, int64_t n, int64_t de, int64_t dx, float scale, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -640,6 +649,7 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   const void* ptrs[] = {E, W12, Q, K, V, ye_add, ye_mul, P, wV, lse};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if (!mask || ((uintptr_t)E12 & 15) || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
+  if (node_off && E12) return MBVAE_EINVAL;        // packed node rows: inference form only
   if (getenv("MBVAE_NO_EDGE_FUSED")) return MBVAE_EUNSUPPORTED;
   // tasks = graphs x blocks of query rows; pick the split that fills the last round of workgroups best
   const int cus = ef_num_cus();
@@ -658,7 +668,7 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
       return MBVAE_EINVAL;
   }
   EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
-                  work_counter};
+                  work_counter, node_off};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;

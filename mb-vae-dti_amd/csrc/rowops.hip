@@ -581,6 +581,78 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
   return mbvae_launch_status();
 }
 
+// Node pooling over packed rows: graph b's valid nodes are rows off[b] .. off[b+1]-1 of x [rows, D]; its n - nb padding
+// nodes all hold row pad_row and are merged analytically.  One 256-thread block per (graph, 256-feature chunk):
+// 64 lanes per row (or D/4), the rest of the block strides over the rows.
+__global__ __launch_bounds__(256) void pool_nodes_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                             const int32_t* __restrict__ off, int64_t pad_row, int n, int D) {
+  __shared__ float sm[256 * 4 * 5];
+  const int lpr = min(64, D / 4), groups = 256 / lpr;
+  const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  const int b = blockIdx.y, c = blockIdx.x * 256 + sub * 4;
+  const bool active = c < D;
+  const int r0 = off[b], nb = off[b + 1] - r0;
+  Moments mo[4]; float mn[4], mx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { mo[q] = {0.f, 0.f, 0.f}; mn[q] = INFINITY; mx[q] = -INFINITY; }
+  if (active) {
+    float cnt = 0.f;
+    for (int l = grp; l < nb; l += groups) {
+      const float4 v = ld4(x + (int64_t)(r0 + l) * D + c);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      cnt += 1.f;
+      const float inv = 1.f / cnt;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float d = vv[q] - mo[q].mean;
+        mo[q].mean += d * inv;
+        mo[q].m2 += d * (vv[q] - mo[q].mean);
+        mn[q] = fminf(mn[q], vv[q]); mx[q] = fmaxf(mx[q], vv[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mo[q].n = cnt;
+    if (grp == 0 && nb < n) {                      // the padding nodes: (n - nb) copies of one row
+      const float4 cv = ld4(x + pad_row * D + c);
+      const float cc[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const Moments pad = {(float)(n - nb), cc[q], 0.f};
+        mom_merge(mo[q], pad);
+        mn[q] = fminf(mn[q], cc[q]); mx[q] = fmaxf(mx[q], cc[q]);
+      }
+    }
+  }
+  float* slot = sm + ((grp * lpr + sub) * 4) * 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float* s = slot + q * 5;
+    s[0] = mo[q].n; s[1] = mo[q].mean; s[2] = mo[q].m2; s[3] = mn[q]; s[4] = mx[q];
+  }
+  for (int stride = groups / 2; stride > 0; stride >>= 1) {
+    __syncthreads();
+    if (grp < stride) {
+      const float* o = sm + (((grp + stride) * lpr + sub) * 4) * 5;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* s = slot + q * 5; const float* t = o + q * 5;
+        Moments a = {s[0], s[1], s[2]}; const Moments bb = {t[0], t[1], t[2]};
+        mom_merge(a, bb); s[0] = a.n; s[1] = a.mean; s[2] = a.m2;
+        s[3] = fminf(s[3], t[3]); s[4] = fmaxf(s[4], t[4]);
+      }
+    }
+  }
+  if (grp == 0 && active) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* s = slot + q * 5;
+      float* o = stats + (int64_t)b * 4 * D;
+      o[c + q] = s[1]; o[D + c + q] = s[3]; o[2 * D + c + q] = s[4];
+      o[3 * D + c + q] = sqrtf(s[2] / (s[0] - 1.f));
+    }
+  }
+}
+
 // x [bs,n,n,64] -> stats [bs,256] as above, reading only the pairs whose two nodes are unmasked; see the kernel.
 int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask, const int32_t* row_idx,
                                const int32_t* nvalid, int64_t bs, int64_t n, int64_t D, hipStream_t stream) {
@@ -592,6 +664,18 @@ int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask
     return MBVAE_ELAUNCH;
   hipLaunchKernelGGL(pool_pairs_fwd_kernel, dim3((unsigned)bs), dim3(1024), smem, stream, x, stats, mask, row_idx, nvalid,
                      (int)n, bs * n * n);
+  return mbvae_launch_status();
+}
+
+int mbvae_pool_stats_nodes_fwd(const float* x, float* stats, const int32_t* node_off, int64_t pad_row, int64_t bs,
+                               int64_t n, int64_t D, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!x || !stats || !node_off || bs <= 0 || n <= 0 || D <= 0 || pad_row < 0) return MBVAE_EINVAL;
+  if ((D & 3) || bs > 65535 || n > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const int lpr = (int)(D / 4 < 64 ? D / 4 : 64);
+  if ((lpr & (lpr - 1)) || (D > 256 && (D % 256))) return MBVAE_EUNSUPPORTED;
+  hipLaunchKernelGGL(pool_nodes_fwd_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)bs), dim3(256), 0, stream, x, stats,
+                     node_off, pad_row, (int)n, (int)D);
   return mbvae_launch_status();
 }
 

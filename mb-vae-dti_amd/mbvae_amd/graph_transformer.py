@@ -84,12 +84,15 @@ class NodeEdgeBlock(nn.Module):
         w, b = self._stacked(key, layers)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None, pack=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
-        use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input)."""
-        n = X.shape[1]
+        use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input).
+        pack (ops.NodePack, inference only): X and newX are packed node rows [rows, dx] instead of [bs, n, dx]."""
+        n = E.shape[1]
         dx = self.dx
         node = dict(mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
+        if pack is not None:            # every packed row is a valid node except the one padding row
+            node = dict(mask=pack.keep, mask_mode=ops.MASK_NODE, n_nodes=pack.keep.shape[1])
         edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
         QKV = self._fused("qkv", X, (self.q, self.k, self.v), **node)            # [bs,n,3dx]
         w12, b12 = self._stacked("e12", (self.e_mul, self.e_add))
@@ -97,7 +100,7 @@ class NodeEdgeBlock(nn.Module):
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head,
-                                                 order=order if edge_norm is not None else None)
+                                                 order=order if edge_norm is not None else None, pack=pack)
         if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
             ln, eps = edge_norm
             newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps,
@@ -107,12 +110,15 @@ class NodeEdgeBlock(nn.Module):
             if not P.requires_grad and not torch.is_grad_enabled():
                 ops.zero_masked_pairs_(P, node_mask)      # the no-gradient attention forward skips padding pairs
             newE = _lin(self.e_out, P, **edge)
-        if torch.is_grad_enabled():
+        if pack is not None:
+            film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
+        elif torch.is_grad_enabled():
             film = yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV
         else:                                  # same arithmetic in two element-wise kernels instead of three
             film = torch.addcmul(yx_add.unsqueeze(1), yx_mul.unsqueeze(1) + 1, wV)
         newX = _lin(self.x_out, film, **node)
-        new_y = yy + self.x_y(X) + _lin(self.e_y.lin, e_stats)
+        x_stats = _lin(self.x_y.lin, ops.pool_stats_nodes(X, pack)) if pack is not None else self.x_y(X)
+        new_y = yy + x_stats + _lin(self.e_y.lin, e_stats)
         new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
         return (newX, newE, new_y, E_alias) if return_edge_alias else (newX, newE, new_y)
 
@@ -134,7 +140,7 @@ class XEyTransformerLayer(nn.Module):
         self.dropout_p = dropout
         self.eps = layer_norm_eps
 
-    def forward(self, X, E, y, node_mask, seeds=None, tile_map=None, order=None):
+    def forward(self, X, E, y, node_mask, seeds=None, tile_map=None, order=None, pack=None):
         """tile_map / order (ops.edge_tile_map / ops.edge_row_order of node_mask, inference only): let the fused edge
         kernels skip or pack away the padding rows.  Both rely on every padding pair row of E holding the same values,
         which holds for E as GraphTransformer feeds it (padding rows enter as zeros and only pass through row-wise
@@ -145,7 +151,8 @@ class XEyTransformerLayer(nn.Module):
         newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
                                               edge_norm=(self.normE1, self.eps) if inference else None,
                                               tile_map=tile_map if inference else None,
-                                              order=order if inference else None)
+                                              order=order if inference else None,
+                                              pack=pack if inference else None)
 
         def norm(ln, x, r):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
@@ -202,8 +209,11 @@ class GraphTransformer(nn.Module):
         if hit is not None and hit["mask"] is node_mask and hit["version"] == node_mask._version:
             if hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
                 hit["order"] = ops.edge_row_order(node_mask, sparse=True)
+                if hit["order"] is not None and os.environ.get("MBVAE_NO_NODE_PACK") is None:
+                    hit["pack"] = ops.NodePack.build(node_mask)      # (one host synchronisation)
             return (None, hit["order"]) if hit["order"] is not None else (hit["tile_map"], None)
-        hit = {"mask": node_mask, "version": node_mask._version, "tile_map": ops.edge_tile_map(node_mask), "order": None}
+        hit = {"mask": node_mask, "version": node_mask._version, "tile_map": ops.edge_tile_map(node_mask), "order": None,
+               "pack": None}
         self.__dict__["_pad_cache"] = hit
         return hit["tile_map"], None
 
@@ -211,7 +221,7 @@ class GraphTransformer(nn.Module):
         """Builds the packed row order of `node_mask` right away (callers that know the same mask tensor is about to be
         used many times, e.g. the reverse-diffusion loop; must run outside HIP graph capture)."""
         self.__dict__["_pad_cache"] = {"mask": node_mask, "version": node_mask._version,
-                                       "tile_map": ops.edge_tile_map(node_mask), "order": None}
+                                       "tile_map": ops.edge_tile_map(node_mask), "order": None, "pack": None}
         return self._padding_shortcuts(node_mask)
 
     def forward(self, X, E, y, node_mask):
@@ -223,18 +233,30 @@ class GraphTransformer(nn.Module):
         def mlp(seq, t, last_act, **kw):
             return _lin(seq[2], _lin(seq[0], t, act=1), act=1 if last_act else 0, **kw)
 
-        hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
-        hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
-        hy = mlp(self.mlp_in_y, y, True)
-        # ragged batch without gradients: the fused inference kernels skip the padding rows of the edge tensor
-        tile_map = order = None
+        # ragged batch without gradients: the fused inference kernels skip the padding rows of the edge tensor, and
+        # the node path runs on the valid nodes only (plus one padding node that stands for all the others)
+        tile_map = order = pack = None
         if not torch.is_grad_enabled() and not self.training:
             tile_map, order = self._padding_shortcuts(node_mask)
+            if order is not None and order.sparse and self.n_layers > 0:
+                pack = self._pad_cache.get("pack")
+        hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
+        if pack is not None:
+            Xflat = X.reshape(-1, X.shape[-1])
+            hX = mlp(self.mlp_in_X, Xflat[pack.rows], True, mask=pack.keep, mask_mode=ops.MASK_NODE, n_nodes=pack.keep.shape[1])
+        else:
+            hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
+        hy = mlp(self.mlp_in_y, y, True)
         for layer in self.tf_layers:
-            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order)
+            hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order, pack=pack)
         if order is not None and order.sparse and self.n_layers > 0:
             ops.zero_masked_pairs_(hE, node_mask)    # the sparse order left most padding rows of hE unwritten
-        oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
+        if pack is not None:                         # back to [bs, n, .]: padding nodes are zero in the output
+            valid = pack.rows[:pack.n_valid]
+            oXp = mlp(self.mlp_out_X, hX, False)[:pack.n_valid] + Xflat[valid, :self.out_dim_X]
+            oX = oXp.new_zeros((Xflat.shape[0], self.out_dim_X)).index_copy_(0, valid, oXp).reshape(*X.shape[:-1], -1)
+        else:
+            oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
         oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
         oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]
         return PlaceHolder(X=oX, E=oE, y=oy)

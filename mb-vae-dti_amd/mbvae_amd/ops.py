@@ -269,24 +269,32 @@ class _EdgeBlock(torch.autograd.Function):
     kernel does not take run the two separate forward kernels; the backward is the same either way."""
 
     @staticmethod
-    def forward(ctx, E, w, b, QKV, ye_add, ye_mul, mask, n_head, order=None):
+    def forward(ctx, E, w, b, QKV, ye_add, ye_mul, mask, n_head, order=None, pack=None):
         E, w, QKV, ye_add, ye_mul = (_f32c(t) for t in (E, w, QKV, ye_add, ye_mul))
-        bs, n, dx3 = QKV.shape
-        dx, de = dx3 // 3, E.shape[-1]
+        bs, n = E.shape[0], E.shape[1]
+        dx, de = QKV.shape[-1] // 3, E.shape[-1]
         M, N = bs * n * n, 2 * dx
         scale = 1.0 / math.sqrt(dx // n_head)
         m8 = _mask_u8(mask)
         dev = E.device
         need_grad = any(ctx.needs_input_grad[:6])
+        if pack is not None and (need_grad or order is None or not order.sparse):
+            raise RuntimeError("packed node rows are an inference-only layout (sparse row order, no gradients)")
         P = torch.empty((bs, n, n, dx), dtype=torch.float32, device=dev)
-        wV = torch.empty((bs, n, dx), dtype=torch.float32, device=dev)
+        if pack is None:
+            wV = torch.empty((bs, n, dx), dtype=torch.float32, device=dev)
+        else:                           # packed rows; the padding row is never written by the kernel and must be finite
+            wV = torch.zeros((QKV.shape[0], dx), dtype=torch.float32, device=dev)
         lse = torch.empty_like(wV)
         E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev) if need_grad else None
         q = QKV.data_ptr()
         fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
                           ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
-                          _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(), bs, n, de, dx, scale, _stream(),
+                          _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(),
+                          0 if pack is None else pack.off.data_ptr(), bs, n, de, dx, scale, _stream(),
                           allow_unsupported=True)
+        if not fused and pack is not None:
+            raise RuntimeError("packed node rows need the fused attention kernel (de = 64, dx = 256, n <= 64)")
         if not fused:
             if E12 is None:
                 E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev)
@@ -316,15 +324,16 @@ class _EdgeBlock(torch.autograd.Function):
         dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV)
         dE, dw, db = _edge_input_grads(E, w, m8, stats, arg, n, has_bias, dE12, dstats, dres,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dE, dw, db, dQKV, dya, dym, None, None, None
+        return dE, dw, db, dQKV, dya, dym, None, None, None, None
 
 
-def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order=None):
+def edge_block(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order=None, pack=None):
     """(P, wV, pooling statistics of E, alias of E): edge_input followed by edge_attention, with the projection
     output kept out of memory whenever the fused forward kernel takes the shape.  Without gradients P is only
     written for valid pairs (see zero_masked_pairs_).  order: a sparse EdgeRowOrder says that E's padding rows hold
-    one common row of which only the order's first padding tile is actually stored (see EdgeRowOrder)."""
-    return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order)
+    one common row of which only the order's first padding tile is actually stored (see EdgeRowOrder).  pack: QKV
+    (and the returned wV) hold packed node rows [rows, .] (see NodePack) instead of [bs, n, .]."""
+    return _EdgeBlock.apply(E, weight, bias, QKV, ye_add, ye_mul, node_mask, n_head, order, pack)
 
 
 # ------------------------------------------------------------------------------------------------ residual + LayerNorm
@@ -425,6 +434,49 @@ def pool_stats_pairs(E, order):
         if not _lib.call("mbvae_pool_stats_pairs_fwd", E.data_ptr(), stats.data_ptr(), order.mask_u8.data_ptr(),
                          order.idx.data_ptr(), order.nvalid.data_ptr(), bs, n, de, _stream(), allow_unsupported=True):
             raise RuntimeError("pool_stats_pairs: unsupported width for a sparse row order")
+    return stats
+
+
+class NodePack:
+    """Packed node rows of a ragged batch for the no-gradient denoiser: `rows` (int64) lists the valid nodes' flat
+    indices b*n + i in ascending order followed, if the batch has padding at all, by ONE padding node (row `pad_row`
+    of the packed tensors: it carries the value all padding nodes share from op to op); `off` (int32 [bs+1]) are the
+    graphs' offsets into the packed rows; `graph` (int64) the graph of each packed row; `keep` (uint8 [1, rows]) is 0
+    for the padding row.  Only for masks that keep a prefix of every graph's nodes (None otherwise).  Building it
+    synchronises with the host once."""
+
+    @staticmethod
+    def build(node_mask):
+        m = node_mask.bool()
+        bs, n = m.shape
+        nb = m.sum(1)
+        if not bool((m == (torch.arange(n, device=m.device).unsqueeze(0) < nb.unsqueeze(1))).all()):
+            return None
+        self = NodePack()
+        flat = m.reshape(-1)
+        valid = flat.nonzero().flatten()
+        pad = (~flat).nonzero().flatten()[:1]
+        self.rows = torch.cat((valid, pad)).contiguous()
+        self.n_valid = int(valid.numel())
+        self.pad_row = self.n_valid if pad.numel() else 0
+        self.off = torch.cat((nb.new_zeros(1), nb.cumsum(0))).to(torch.int32).contiguous()
+        self.graph = torch.div(self.rows, n, rounding_mode="floor")
+        keep = torch.ones(self.rows.numel(), dtype=torch.uint8, device=m.device)
+        if pad.numel():
+            keep[-1] = 0
+        self.keep = keep.reshape(1, -1)
+        self.bs, self.n = bs, n
+        return self
+
+
+def pool_stats_nodes(Xp, pack):
+    """[bs, 4*dx] = mean | min | max | unbiased std over all n nodes of every graph from packed rows Xp (NodePack):
+    the padding nodes enter as (n - nb) copies of the pack's padding row.  No gradients."""
+    Xp = _f32c(Xp, "Xp")
+    D = Xp.shape[-1]
+    stats = torch.empty((pack.bs, 4 * D), dtype=torch.float32, device=Xp.device)
+    _lib.call("mbvae_pool_stats_nodes_fwd", Xp.data_ptr(), stats.data_ptr(), pack.off.data_ptr(), pack.pad_row, pack.bs,
+              pack.n, D, _stream())
     return stats
 
 

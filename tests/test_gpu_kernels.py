@@ -919,7 +919,7 @@ def test_denoiser_inference_padding_shortcuts_are_exact():
         assert net._pad_cache["order"] is None and net._pad_cache["tile_map"] is not None
         a2 = net(Xin, E0, yin, mask)
     assert torch.equal(a.E, a1.E)
-    assert net._pad_cache["order"] is not None and net._pad_cache["order"].sparse
+    assert net._pad_cache["order"] is not None and net._pad_cache["order"].sparse and net._pad_cache["pack"] is not None
     # the sparse order pools the padding pairs analytically: same mathematics, different rounding
     assert_close(a2.X, a.X, rtol=2e-5, what="X (sparse order)"); assert_close(a2.E, a.E, rtol=2e-5, what="E (sparse order)")
     assert_close(a2.y, a.y, rtol=2e-5, what="y (sparse order)")
