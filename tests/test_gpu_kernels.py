@@ -926,3 +926,44 @@ def test_denoiser_inference_padding_shortcuts_are_exact():
     c = net(Xin, E0, yin, mask)                      # gradients enabled: training-form kernels
     assert_close(a.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(a.E, c.E.detach(), rtol=2e-5, what="E")
     assert_close(a.y, c.y.detach(), rtol=2e-5, what="y")
+
+
+def test_packed_node_rows(ops):
+    """NodePack: packed node pooling equals the dense pooling (padding nodes = copies of one row); masks that do not
+    keep a prefix of the nodes get no pack and the denoiser still matches its gradient-mode forward."""
+    g = torch.Generator().manual_seed(11)
+    bs, n, D = 6, 23, 256
+    sizes = torch.tensor([23, 1, 12, 23, 7, 2])
+    mask = (torch.arange(n)[None, :] < sizes[:, None]).cuda()
+    pack = ops.NodePack.build(mask)
+    assert pack is not None and pack.n_valid == int(sizes.sum()) and pack.rows.numel() == pack.n_valid + 1
+    assert pack.off.tolist() == [0] + sizes.cumsum(0).tolist() and int(pack.keep.sum()) == pack.n_valid
+    X = torch.randn(bs, n, D, generator=g).cuda()
+    X[~mask] = X[1, 5].clone()                           # all padding nodes hold one row
+    dense = ops.pool_stats(X)
+    packed = ops.pool_stats_nodes(X.reshape(-1, D)[pack.rows].contiguous(), pack)
+    assert_close(packed, dense, rtol=1e-5, what="packed node pooling")
+    full = torch.ones(3, 9, dtype=torch.bool).cuda()      # no padding at all: no padding row either
+    pf = ops.NodePack.build(full)
+    assert pf.rows.numel() == 27 and pf.n_valid == 27
+    Xf = torch.randn(3, 9, 64, generator=g).cuda()
+    assert_close(ops.pool_stats_nodes(Xf.reshape(-1, 64), pf), ops.pool_stats(Xf), rtol=1e-5, what="packed pooling, full graphs")
+    holes = mask.clone(); holes[0, 3] = False
+    assert ops.NodePack.build(holes) is None
+    from mbvae_amd.graph_transformer import GraphTransformer
+    from mbvae_amd.trainstep import CFG3, synthetic_graphs
+    cfg = dict(CFG3); cfg["n_layers"] = 2
+    torch.manual_seed(4)
+    net = GraphTransformer(**cfg).cuda().eval()
+    X0, E0, _ = synthetic_graphs(bs, n, "cuda", g)
+    hm = holes
+    Xin = torch.cat((X0, torch.randn(bs, n, 8, generator=g).cuda()), 2) * hm.unsqueeze(-1)
+    E0 = E0 * (hm.unsqueeze(1) & hm.unsqueeze(2)).unsqueeze(-1)
+    yin = torch.randn(bs, 1037, generator=g).cuda()
+    with torch.no_grad():
+        net(Xin, E0, yin, hm)
+        b = net(Xin, E0, yin, hm)                        # second sight: sparse row order, but no node pack
+    assert net._pad_cache["order"] is not None and net._pad_cache["pack"] is None
+    c = net(Xin, E0, yin, hm)
+    assert_close(b.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(b.E, c.E.detach(), rtol=2e-5, what="E")
+    assert_close(b.y, c.y.detach(), rtol=2e-5, what="y")
