@@ -211,6 +211,8 @@ class GraphTransformer(nn.Module):
                 hit["order"] = ops.edge_row_order(node_mask, sparse=True)
                 if hit["order"] is not None and os.environ.get("MBVAE_NO_NODE_PACK") is None:
                     hit["pack"] = ops.NodePack.build(node_mask)      # (one host synchronisation)
+                    if hit["pack"] is not None:                      # the valid pair rows, for the edge in / out MLPs
+                        hit["pack"].pair_rows = hit["order"].idx[:int(hit["order"].nvalid[0])].long()
             return (None, hit["order"]) if hit["order"] is not None else (hit["tile_map"], None)
         hit = {"mask": node_mask, "version": node_mask._version, "tile_map": ops.edge_tile_map(node_mask), "order": None,
                "pack": None}
@@ -240,7 +242,13 @@ class GraphTransformer(nn.Module):
             tile_map, order = self._padding_shortcuts(node_mask)
             if order is not None and order.sparse and self.n_layers > 0:
                 pack = self._pad_cache.get("pack")
-        hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
+        if pack is not None:            # the edge input MLP on the valid pairs only (sym_mask zeroes the others anyway)
+            Eflat = E.reshape(-1, E.shape[-1])
+            hv = mlp(self.mlp_in_E, Eflat[pack.pair_rows], True)
+            hE = hv.new_zeros((Eflat.shape[0], hv.shape[-1])).index_copy_(0, pack.pair_rows, hv)
+            hE = ops.sym_mask(hE.reshape(*E.shape[:-1], -1), node_mask)
+        else:
+            hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
         if pack is not None:
             Xflat = X.reshape(-1, X.shape[-1])
             hX = mlp(self.mlp_in_X, Xflat[pack.rows], True, mask=pack.keep, mask_mode=ops.MASK_NODE, n_nodes=pack.keep.shape[1])
@@ -249,7 +257,11 @@ class GraphTransformer(nn.Module):
         hy = mlp(self.mlp_in_y, y, True)
         for layer in self.tf_layers:
             hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order, pack=pack)
-        if order is not None and order.sparse and self.n_layers > 0:
+        if pack is not None:                         # the edge output MLP on the valid pairs only, likewise
+            ov = mlp(self.mlp_out_E, hE.reshape(-1, hE.shape[-1])[pack.pair_rows], False)
+            oE = ov.new_zeros((Eflat.shape[0], ov.shape[-1])).index_copy_(0, pack.pair_rows, ov)
+            oE = ops.sym_mask(oE.reshape(*E.shape[:-1], -1), node_mask, skip=E, zero_diag=True)
+        elif order is not None and order.sparse and self.n_layers > 0:
             ops.zero_masked_pairs_(hE, node_mask)    # the sparse order left most padding rows of hE unwritten
         if pack is not None:                         # back to [bs, n, .]: padding nodes are zero in the output
             valid = pack.rows[:pack.n_valid]
@@ -257,6 +269,7 @@ class GraphTransformer(nn.Module):
             oX = oXp.new_zeros((Xflat.shape[0], self.out_dim_X)).index_copy_(0, valid, oXp).reshape(*X.shape[:-1], -1)
         else:
             oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
-        oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
+        if pack is None:
+            oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
         oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]
         return PlaceHolder(X=oX, E=oE, y=oy)
