@@ -967,3 +967,48 @@ def test_packed_node_rows(ops):
     c = net(Xin, E0, yin, hm)
     assert_close(b.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(b.E, c.E.detach(), rtol=2e-5, what="E")
     assert_close(b.y, c.y.detach(), rtol=2e-5, what="y")
+
+
+def test_sample_batch_full_width_packed_path(monkeypatch):
+    """sample_batch at the reference widths (the packed inference path: sparse row order, packed node rows, optional
+    HIP graph): well-formed molecules, and the same molecules as the dense evaluation of every padded row for the
+    same random draws (a draw could only differ where two classes are within rounding of a tie)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd.full import FullDTIModel
+    from mbvae_amd.trainstep import ATOM_WEIGHTS, CFG3, ME, MX, VALENCIES
+    cfg = dict(CFG3); cfg["n_layers"] = 2
+    infos = {"general": {"atom_types": ["C", "O", "P", "N", "S"], "max_n_nodes": 64, "atom_valencies": list(VALENCIES),
+                         "atom_weights": list(ATOM_WEIGHTS), "max_weight": 1000},
+             "dataset": {"node_count_distribution": {"9": 1, "20": 1}, "node_marginals": list(MX), "edge_marginals": list(ME)}}
+    torch.manual_seed(0)
+    model = FullDTIModel(phase="pretrain_drug", finetune_score=None, learning_rate=5e-4, weight_decay=1e-4, scheduler="const",
+                         weights=[1.0, 0.001, 0.0, 3.0], dti_weights=None, diff_weights=[1, 5], contrastive_temp=0.1,
+                         drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 32}, target_features={}, embedding_dim=1024,
+                         hidden_dim=32, factor=2, n_layers=1, activation="relu", dropout=0.1, bias=True,
+                         encoder_type="transformer", aggregator_type="attentive", diffusion_steps=4, sample_every_val=5,
+                         val_samples_per_embedding=2, test_samples_per_embedding=2, graph_transformer_kwargs=cfg,
+                         dataset_infos=infos).cuda().eval()
+    emb = torch.randn(7, 1024, device="cuda")
+    sizes = torch.tensor([30, 9, 17, 33, 12, 5, 21])
+
+    def run(**kw):
+        torch.manual_seed(123)
+        return model.sample_batch(emb, num_nodes=sizes, num_samples_per_embedding=2, return_graphs=True, **kw)
+
+    packed = run()
+    assert model.drug_decoder._pad_cache["pack"] is not None and model.drug_decoder._pad_cache["order"].sparse
+    for grp, n in zip(packed, sizes.tolist()):
+        for atoms, bonds in grp:
+            assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
+            assert int(atoms.min()) >= 0 and int(atoms.max()) < 5 and int(bonds.max()) < 5 and int(bonds.diagonal().abs().sum()) == 0
+    monkeypatch.setenv("MBVAE_NO_ROW_ORDER", "1")
+    dense = run()
+    monkeypatch.delenv("MBVAE_NO_ROW_ORDER")
+    same = sum(int(torch.equal(a1, a2) and torch.equal(b1, b2)) for g1, g2 in zip(packed, dense) for (a1, b1), (a2, b2) in zip(g1, g2))
+    assert same >= 13, f"only {same} of 14 molecules agree with the dense evaluation"
+    for kw in (dict(use_graph=True), dict(balance=True, use_graph=True), dict(size_buckets=2)):
+        for grp, n in zip(run(**kw), sizes.tolist()):
+            for atoms, bonds in grp:
+                assert atoms.shape == (n,) and bonds.shape == (n, n) and torch.equal(bonds, bonds.T)
+                assert int(atoms.min()) >= 0 and int(atoms.max()) < 5 and int(bonds.max()) < 5
