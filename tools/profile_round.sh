@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01d
+O=$R/gpurun_out/prof_r01e
 rm -rf $O; mkdir -p $O
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
 export TRAFFIC_MANIFEST=$O/manifest.json
