@@ -209,7 +209,8 @@ class GraphTransformer(nn.Module):
         if hit is not None and hit["mask"] is node_mask and hit["version"] == node_mask._version:
             if hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
                 hit["order"] = ops.edge_row_order(node_mask, sparse=True)
-                if hit["order"] is not None and os.environ.get("MBVAE_NO_NODE_PACK") is None:
+                # (packed node rows go through the fused attention kernel, which takes at most 64 nodes per graph)
+                if hit["order"] is not None and node_mask.shape[1] <= 64 and os.environ.get("MBVAE_NO_NODE_PACK") is None:
                     hit["pack"] = ops.NodePack.build(node_mask)      # (one host synchronisation)
                     if hit["pack"] is not None:                      # the valid pair rows, for the edge in / out MLPs
                         hit["pack"].pair_rows = hit["order"].idx[:int(hit["order"].nvalid[0])].long()

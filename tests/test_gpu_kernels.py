@@ -965,6 +965,17 @@ def test_packed_node_rows(ops):
         b = net(Xin, E0, yin, hm)                        # second sight: sparse row order, but no node pack
     assert net._pad_cache["order"] is not None and net._pad_cache["pack"] is None
     c = net(Xin, E0, yin, hm)
+    # more than 64 nodes per graph: the fused attention kernel does not take the shape, so no node pack either
+    big = (torch.arange(70)[None, :] < torch.tensor([[70], [31]])).cuda()
+    Xb, Eb, _ = synthetic_graphs(2, 70, "cuda", g)
+    Xb = torch.cat((Xb, torch.randn(2, 70, 8, generator=g).cuda()), 2) * big.unsqueeze(-1)
+    Eb = Eb * (big.unsqueeze(1) & big.unsqueeze(2)).unsqueeze(-1)
+    with torch.no_grad():
+        net(Xb, Eb, yin[:2], big)
+        b2 = net(Xb, Eb, yin[:2], big)
+    assert net._pad_cache["order"] is not None and net._pad_cache["pack"] is None
+    c2 = net(Xb, Eb, yin[:2], big)
+    assert_close(b2.X, c2.X.detach(), rtol=2e-5, what="X, n = 70"); assert_close(b2.E, c2.E.detach(), rtol=2e-5, what="E, n = 70")
     assert_close(b.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(b.E, c.E.detach(), rtol=2e-5, what="E")
     assert_close(b.y, c.y.detach(), rtol=2e-5, what="y")
 
