@@ -1,4 +1,4 @@
-"""Benchmark: graphs/sec of the denoiser train step (BASELINE config 3) on N MI355X of one node.
+"""Benchmark: graphs/sec of the denoiser train step (256 graphs x 64 atoms, 8 layers) on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \

@@ -12,7 +12,7 @@ from .diffusion import PredefinedNoiseScheduleDiscrete, exp_draws
 from .features import ExtraFeatures, ExtraMolecularFeatures
 from .graph_transformer import GraphTransformer
 
-CFG3 = dict(  # BASELINE config 3: 8 layers, 5 atom / 5 bond classes, reference widths
+CFG3 = dict(  # the benchmark denoiser: 8 layers, 5 atom / 5 bond classes, reference widths
     n_layers=8, input_dims={"X": 13, "E": 5, "y": 1037}, output_dims={"X": 5, "E": 5, "y": 1024},
     hidden_mlp_dims={"X": 256, "E": 128, "y": 2048},
     hidden_dims={"dx": 256, "de": 64, "dy": 1024, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 1024})
