@@ -85,11 +85,14 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
  * node_off (NULL, or int32 [bs+1]; inference form only): packed node rows.  Q, K, V, wV and lse then hold only the
  * valid nodes, graph b's nodes 0 .. nb-1 at rows node_off[b] .. node_off[b+1]-1 (the mask must keep exactly the first
  * nb nodes of graph b); rows of masked nodes do not exist and are neither read nor written.  E and P stay dense.
+ * graph_order (NULL, or int32 [bs], a permutation of 0..bs-1): the order in which the graphs' tasks are handed out;
+ * largest graphs first evens out a ragged batch without reordering it.  The results do not depend on it.
  * MBVAE_EUNSUPPORTED unless de == 64, dx == 256 and n <= 64: callers then use the two separate entry points. */
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
                          float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
-                         int64_t bs, int64_t n, int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
+                         const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                         mbvae_stream_t stream);
 
 /* ---- edge feed-forward block, inference form ----------------------------------------------------------
  * Replaces `normE2(E + linE2(relu(linE1(E))))` of XEyTransformerLayer.forward (graph_transformer.py:139-142) when

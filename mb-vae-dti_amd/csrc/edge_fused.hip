@@ -26,6 +26,7 @@ struct EdgeFusedArgs {
   int bs, n; float scale; int ichunks;
   int* queue;      // optional work counter (zeroed before the launch): workgroups take tasks in order as they finish
   const int* node_off;   // optional [bs+1]: Q, K, V, wV, lse hold only the valid nodes, graph b's at rows node_off[b]..
+  const int* graph_order;   // optional [bs]: the k-th group of tasks works on graph graph_order[k] (largest graphs first)
 };
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       task += gridDim.x;
     }
     if (task >= ntasks) break;
-    const int b = task / a.ichunks, ic = task - b * a.ichunks;
+    const int bt = task / a.ichunks, ic = task - bt * a.ichunks;
+    const int b = a.graph_order ? a.graph_order[bt] : bt;
     const int i0 = ic * ipc, i1 = min(n, i0 + ipc);
     const int64_t node = (int64_t)b * n;
     // packed node rows (inference, masks that keep a prefix of each graph's nodes): node (b, i) is row pnode + i for
@@ -637,11 +639,14 @@ extern "C" {
 // workgroups then draw (graph, query-row block) tasks from it in order instead of a fixed round robin.
 // node_off: NULL, or int32 [bs+1] (inference form only, masks that keep a prefix of every graph's nodes): Q, K, V, wV
 // and lse then hold the valid nodes only, graph b's nodes 0..nb-1 at rows node_off[b] .. node_off[b+1]-1.
+// graph_order: NULL, or a permutation of 0..bs-1 (int32): the order in which the graphs' tasks are handed out (largest
+// first, together with work_counter, gives every workgroup a similar amount of work whatever the batch order).
 // MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.
 int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
                          const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
                          float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
-                         int64_t bs, int64_t n, int64_t de, int64_t dx, float scale, hipStream_t stream) {
+                         const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                         hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -668,7 +673,7 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
       return MBVAE_EINVAL;
   }
   EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
-                  work_counter, node_off};
+                  work_counter, node_off, graph_order};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;

@@ -21,7 +21,7 @@ SIGNATURES = {
     "mbvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
     "mbvae_edge_attn_fwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 6 + [_L, _L, _L, _F, _P],
     "mbvae_edge_attn_bwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P],
-    "mbvae_edge_fused_fwd": [_P] * 6 + [_L] + [_P] * 9 + [_L, _L, _L, _L, _F, _P],
+    "mbvae_edge_fused_fwd": [_P] * 6 + [_L] + [_P] * 10 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_ffn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],
     "mbvae_ln_residual_fwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P],

@@ -291,8 +291,8 @@ class _EdgeBlock(torch.autograd.Function):
         fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
                           ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
                           _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(),
-                          0 if pack is None else pack.off.data_ptr(), bs, n, de, dx, scale, _stream(),
-                          allow_unsupported=True)
+                          0 if pack is None else pack.off.data_ptr(), 0 if pack is None else pack.by_size.data_ptr(),
+                          bs, n, de, dx, scale, _stream(), allow_unsupported=True)
         if not fused and pack is not None:
             raise RuntimeError("packed node rows need the fused attention kernel (de = 64, dx = 256, n <= 64)")
         if not fused:
@@ -442,7 +442,8 @@ class NodePack:
     indices b*n + i in ascending order followed, if the batch has padding at all, by ONE padding node (row `pad_row`
     of the packed tensors: it carries the value all padding nodes share from op to op); `off` (int32 [bs+1]) are the
     graphs' offsets into the packed rows; `graph` (int64) the graph of each packed row; `keep` (uint8 [1, rows]) is 0
-    for the padding row.  Only for masks that keep a prefix of every graph's nodes (None otherwise).  Building it
+    for the padding row; `by_size` (int32 [bs]) lists the graphs from the largest to the smallest, the order in which
+    the attention kernel hands out its per-graph tasks.  Only for masks that keep a prefix of every graph's nodes (None otherwise).  Building it
     synchronises with the host once."""
 
     @staticmethod
@@ -461,6 +462,7 @@ class NodePack:
         self.pad_row = self.n_valid if pad.numel() else 0
         self.off = torch.cat((nb.new_zeros(1), nb.cumsum(0))).to(torch.int32).contiguous()
         self.graph = torch.div(self.rows, n, rounding_mode="floor")
+        self.by_size = torch.argsort(nb, descending=True, stable=True).to(torch.int32).contiguous()   # largest graphs first
         keep = torch.ones(self.rows.numel(), dtype=torch.uint8, device=m.device)
         if pad.numel():
             keep[-1] = 0
