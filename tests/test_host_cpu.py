@@ -27,6 +27,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.mbvae_masked_ce_workspace() > 0
 
 
+def test_header_declarations_match_the_implementations(tmp_path):
+    """Every .hip source compiled (syntax only) behind include/mbvae_hip.h: a declaration whose parameters differ from
+    the definition is a conflicting-types error."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "mb-vae-dti_amd", "csrc")
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith(".hip")):
+        tu = tmp_path / ("chk_" + name)
+        tu.write_text('#include <hip/hip_runtime.h>\n#include "%s"\n#include "%s"\n'
+                      % (os.path.join(root, "include", "mbvae_hip.h"), os.path.join(csrc, name)))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I", csrc, str(tu)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "error" not in r.stderr, f"{name}:\n{r.stderr[-2000:]}"
+
+
 def test_product_path_refuses_cpu_tensors():
     from mbvae_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
