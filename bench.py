@@ -148,8 +148,11 @@ def main():
         # HBM with their algorithmic bytes per launch; both over the HIP-event average launch duration.
         s = 4
         dx = CFG3["hidden_dims"]["dx"]
+        de = CFG3["hidden_dims"]["de"]
         ea_bytes = {"mbvae_edge_attn_bwd": s * (5 * bs * n * n * dx + 8 * bs * n * dx),      # E1,E2,dP in; dE1,dE2 out
-                    "mbvae_edge_attn_fwd": s * (3 * bs * n * n * dx + 4 * bs * n * dx + 2 * bs * dx) + bs * n}
+                    "mbvae_edge_attn_fwd": s * (3 * bs * n * n * dx + 4 * bs * n * dx + 2 * bs * dx) + bs * n,
+                    # projection inside the attention forward, training form: E in; E1|E2 and P out
+                    "mbvae_edge_fused_fwd": s * (bs * n * n * (de + 3 * dx) + 4 * bs * n * dx)}
         cands = []
         for (name, tag), evs in profile.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
