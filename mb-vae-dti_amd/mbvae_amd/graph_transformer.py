@@ -207,7 +207,9 @@ class GraphTransformer(nn.Module):
         version counter catches in-place changes."""
         hit = self.__dict__.get("_pad_cache")
         if hit is not None and hit["mask"] is node_mask and hit["version"] == node_mask._version:
-            if hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None:
+            # (never while a HIP graph is being captured: building the node pack synchronises with the host)
+            if (hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None
+                    and not torch.cuda.is_current_stream_capturing()):
                 hit["order"] = ops.edge_row_order(node_mask, sparse=True)
                 # (packed node rows go through the fused attention kernel, which takes at most 64 nodes per graph)
                 if hit["order"] is not None and node_mask.shape[1] <= 64 and os.environ.get("MBVAE_NO_NODE_PACK") is None:
