@@ -185,6 +185,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
         const unsigned inl = (rows_here >= 32 ? 0xffffffffu : ((1u << rows_here) - 1u)) >> (4 * h);    \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          /* inference: a group of 8 keys (4 per half-wave) without a valid one needs nothing (wave-uniform test) */ \
+          if (!WRITE_E12 && ((km32 >> (8 * (v >> 2))) & 0xffu) == 0u) { y[v] = -INFINITY; continue; }  \
           const bool key_ok = (kml >> rr) & 1u, in = (inl >> rr) & 1u;                                 \
           const bool pair_ok = qi_ok && key_ok;                                                        \
           const float e1 = pair_ok ? acc1[v] : 0.f, e2 = pair_ok ? acc2[v] : 0.f;                      \
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           l_run *= corr; av_run *= corr;                                                               \
           _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                             \
             const int rr = (v & 3) + 8 * (v >> 2);                                                     \
+            if (!WRITE_E12 && ((km32 >> (8 * (v >> 2))) & 0xffu) == 0u) continue;                      \
             const bool key_ok = (kml >> rr) & 1u;                                                      \
             const float w = key_ok ? __expf(y[v] - m_new) : 0.f;                                       \
             const float vv = key_ok ? Vp[rr * 256] : 0.f;                                              \
