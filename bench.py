@@ -1,6 +1,6 @@
 """Benchmark: graphs/sec of the denoiser train step (256 graphs x 64 atoms, 8 layers) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps 5 --warmup 2          (N > 1: starts one worker process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,6 +11,8 @@ on 256 synthetic graphs of 64 atoms per GPU (weak scaling).  Rank 0 prints ONE J
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,26 +28,37 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak
 
 
 def cpu_baseline(cfg, n, seconds=20.0):
-    """The CPU oracle (this repo's restatement of the reference path) timed on the host cores: denoiser forward +
-    masked CE + backward, fp32, eval-mode dropout, bounded sample (batch 8, as many steps as fit in `seconds`)."""
-    from oracle import denoiser as O_den, heads as O_heads
+    """The CPU oracle (this repo's restatement of the reference path) timed on the host cores over the SAME step the
+    GPU line measures: forward noising, extra features (cycle counts + eigh), denoiser forward, masked CE, backward,
+    AdamW(amsgrad); fp32, batch 8 (the unfused path keeps ~12 [bs,n,n,256] tensors per layer), as many steps as fit in
+    `seconds`.  The oracle has no dropout (the reference's 9 dropouts per layer are element-wise passes it skips)."""
+    from oracle import denoiser as O_den, diffusion as O_dif, features as O_feat, heads as O_heads
     from mbvae_amd.graph_transformer import GraphTransformer
-    from mbvae_amd.trainstep import synthetic_graphs
+    from mbvae_amd.trainstep import ATOM_WEIGHTS, ME, MX, VALENCIES, synthetic_graphs
     torch.manual_seed(0)
     bs = 8
     net = GraphTransformer(**cfg)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=5e-4, weight_decay=1e-4, amsgrad=True)
     g = torch.Generator().manual_seed(0)
     X0, E0, mask = synthetic_graphs(bs, n, "cpu", g)
-    Xin = torch.cat((X0, torch.randn(bs, n, cfg["input_dims"]["X"] - X0.shape[-1], generator=g)), 2)
-    yin = torch.randn(bs, cfg["input_dims"]["y"], generator=g)
+    cond = torch.randn(bs, cfg["output_dims"]["y"], generator=g)
+    sch = O_dif.Schedule(500)
+    mx, me = torch.tensor(MX), torch.tensor(ME)
     heads = cfg["hidden_dims"]["n_head"]
 
     def one():
-        oX, oE, _ = O_den.graph_transformer(params, Xin, E0, yin, mask, cfg["n_layers"], heads, cfg["output_dims"])
+        t_int = torch.randint(0, 501, (bs, 1), generator=g).float()
+        eX = torch.empty(bs * n, len(MX)).exponential_(1, generator=g)
+        eE = torch.empty(bs * n * n, len(ME)).exponential_(1, generator=g)
+        Xt, Et, npar, _, _ = O_dif.apply_noise(sch, mx, me, X0, E0, mask, t_int, eX, eE)
+        Xe, ye = O_feat.extra_features(Xt, Et, npar["t"], mask, torch.randn(bs, n, generator=g), 64, list(VALENCIES),
+                                       list(ATOM_WEIGHTS), 1000.0)
+        oX, oE, _ = O_den.graph_transformer(params, torch.cat((Xt, Xe), 2), Et, torch.cat((cond, ye), 1), mask,
+                                            cfg["n_layers"], heads, cfg["output_dims"])
         O_heads.reconstruction_loss(oX, oE, X0, E0, [1, 5]).backward()
-        for p in params.values():
-            p.grad = None
+        opt.step()
+        opt.zero_grad(set_to_none=True)
 
     one()  # warm-up
     steps, t0 = 0, time.perf_counter()
@@ -56,8 +69,8 @@ def cpu_baseline(cfg, n, seconds=20.0):
         if el > seconds or steps >= 8:
             break
     return {"value": round(bs * steps / el, 3), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"CPU oracle (oracle/denoiser.py + heads.py), denoiser fwd + masked CE + bwd, batch {bs} x {steps} steps, "
-                      f"n={n}, {cfg['n_layers']} layers, fp32, no optimizer / noising / extra features"}
+            "sample": f"CPU oracle (oracle/*.py): noise + extra features + denoiser fwd + masked CE + bwd + AdamW(amsgrad), "
+                      f"batch {bs} x {steps} steps, n={n}, {cfg['n_layers']} layers, fp32, no dropout"}
 
 
 def kernel_table(profile):
@@ -73,6 +86,27 @@ def kernel_table(profile):
     return rows
 
 
+def launch_workers(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (this same script, one per GPU,
+    rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, wait for them, and pass on the worst
+    exit status.  Rank 0 prints the JSON line on the inherited stdout."""
+    have = torch.cuda.device_count()            # (counting devices does not initialise the GPU runtime)
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max((abs(c) for c in codes), default=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +117,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_workers(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

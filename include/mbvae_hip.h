@@ -6,7 +6,9 @@
  *   - nothing is allocated, freed or synchronised: outputs and workspaces are caller-owned, work is
  *     enqueued on `stream` and the call returns immediately;
  *   - return value: 0 ok, -1 invalid argument, -2 unsupported shape, -3 launch failure; no exceptions;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant and thread-safe.  The library keeps no mutable state per call; process-wide it holds (a) tables
+ *     filled once and read-only afterwards (compute-unit count and kernel LDS limits per device) and (b) the tuning
+ *     switches of mbvae_set_option below (relaxed atomics).
  * The reference has no native interface; each entry point replaces the sequence of PyTorch ops cited
  * next to it (paths relative to the reference repository root).
  */
@@ -23,6 +25,16 @@ typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
 #define MBVAE_MASK_NONE 0
 #define MBVAE_MASK_NODE 1 /* row r = node (b,i):   keep iff mask[r] */
 #define MBVAE_MASK_EDGE 2 /* row r = pair (b,i,j): keep iff mask[b*n+i] && mask[b*n+j] */
+
+/* ---- tuning switches ------------------------------------------------------------------------------------
+ * No counterpart in the reference.  Process-wide switches that choose between equivalent HIP routes (kernel A/B
+ * timing, parity tests of the fallback kernels; never a CPU path).  Names: "NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64",
+ * "NO_TSWGRAD", "NO_TSWGRAD2", "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED" (0 / 1) and
+ * "GEMM_TILE" (-1 automatic, 0 = 64x64, 1 = 128x64, 2 = 128x128).  Each starts from the environment variable
+ * MBVAE_<NAME>, read once.  mbvae_set_option: 0, or -1 for an unknown name.  mbvae_get_option: the value (-1 for an
+ * unknown name).  A change takes effect at the next entry-point call. */
+int mbvae_set_option(const char* name, int value);
+int mbvae_get_option(const char* name);
 
 /* ---- Linear layers on the matrix cores (fp32 MFMA) -------------------------------------------------
  * Replaces nn.Linear forward/backward plus the `* x_mask`, `* e_mask1 * e_mask2`, ReLU and Dropout that

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 
 #define MBVAE_OK 0
 #define MBVAE_EINVAL (-1)
@@ -24,6 +26,73 @@ static inline int mbvae_launch_status() {
 // backward pass regenerates the keep-mask instead of storing it.  32-bit on purpose: the epilogues that call this
 // once per output element sit next to the MFMA stream, where 64-bit integer multiplies would make the vector ALU the
 // bottleneck.  The seed and the upper index half (wave-uniform in practice) fold into one word on the scalar unit.
+// Process-wide tuning switches.  Each starts from its environment variable (MBVAE_<NAME>, read ONCE when the first
+// entry point runs; the per-call paths never call getenv) and can be changed afterwards with mbvae_set_option():
+// they are plain atomics read with relaxed loads, so changing one while kernels are being issued from another
+// thread merely takes effect at some later call.  They select between equivalent HIP routes (kernel A/B tests,
+// parity tests of the fallback kernels), never a CPU path.
+enum MbvaeOption {
+  MBVAE_OPT_NO_TSGEMM, MBVAE_OPT_NO_TSGEMM2, MBVAE_OPT_TSGEMM_N64, MBVAE_OPT_NO_TSWGRAD, MBVAE_OPT_NO_TSWGRAD2,
+  MBVAE_OPT_NO_EDGE_FUSED, MBVAE_OPT_NO_EDGE_FFN, MBVAE_OPT_NO_SMALLM, MBVAE_OPT_NO_EDGE_TRAIN_FUSED,
+  MBVAE_OPT_GEMM_TILE,     // -1: automatic; 0 = 64x64, 1 = 128x64, 2 = 128x128
+  MBVAE_OPT_COUNT
+};
+inline const char* const* mbvae_option_names() {
+  static const char* const names[MBVAE_OPT_COUNT] = {"NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64", "NO_TSWGRAD", "NO_TSWGRAD2",
+                                                     "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
+                                                     "GEMM_TILE"};
+  return names;
+}
+struct MbvaeOptions {
+  std::atomic<int> v[MBVAE_OPT_COUNT];
+  MbvaeOptions() {
+    for (int i = 0; i < MBVAE_OPT_COUNT; ++i) {
+      char name[64];
+      snprintf(name, sizeof(name), "MBVAE_%s", mbvae_option_names()[i]);
+      const char* e = getenv(name);
+      int val = i == MBVAE_OPT_GEMM_TILE ? -1 : 0;
+      if (e) val = i == MBVAE_OPT_GEMM_TILE ? (*e ? atoi(e) : -1) : 1;
+      v[i].store(val, std::memory_order_relaxed);
+    }
+  }
+};
+inline MbvaeOptions& mbvae_options() {
+  static MbvaeOptions o;
+  return o;
+}
+inline int mbvae_opt(int id) { return mbvae_options().v[id].load(std::memory_order_relaxed); }
+
+// Compute units of the current device (queried once per device, then a table lookup).
+inline int mbvae_num_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::atomic<int>& slot = cus[dev & 63];
+  int c = slot.load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    slot.store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
+// Raises `kernel`'s dynamic-LDS limit to the device maximum once per device (the attribute is a cap, not an
+// allocation).  One static flag word per call site; evaluates to false if the runtime call fails.
+#define MBVAE_LDS_LIMIT 163840          /* 160 KB per workgroup on gfx950 */
+#define MBVAE_ALLOW_BIG_LDS(kernel)                                                                                   \
+  ([&]() -> bool {                                                                                                    \
+    static std::atomic<unsigned long long> done_{0ull};                                                               \
+    int dev_ = 0;                                                                                                     \
+    if (hipGetDevice(&dev_) != hipSuccess) return false;                                                              \
+    const unsigned long long bit_ = 1ull << (dev_ & 63);                                                              \
+    if (done_.load(std::memory_order_acquire) & bit_) return true;                                                    \
+    if (hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MBVAE_LDS_LIMIT) !=    \
+        hipSuccess)                                                                                                   \
+      return false;                                                                                                   \
+    done_.fetch_or(bit_, std::memory_order_release);                                                                  \
+    return true;                                                                                                      \
+  }())
+
 __device__ __forceinline__ float mbvae_u01(uint64_t seed, uint64_t idx) {
   const uint32_t s = (uint32_t)seed * 0x9E3779B9u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ (uint32_t)(idx >> 32) * 0xC2B2AE3Du;
   uint32_t x = (uint32_t)idx ^ s;

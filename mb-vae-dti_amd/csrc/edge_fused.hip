@@ -623,15 +623,7 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
 #undef EO_GROUP
 }
 
-static int ef_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
-  return cus;
-}
+static int ef_num_cus() { return mbvae_num_cus(); }
 
 extern "C" {
 
@@ -658,7 +650,7 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if (!mask || ((uintptr_t)E12 & 15) || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
   if (node_off && E12) return MBVAE_EINVAL;        // packed node rows: inference form only
-  if (getenv("MBVAE_NO_EDGE_FUSED")) return MBVAE_EUNSUPPORTED;
+  if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
   // tasks = graphs x blocks of query rows; pick the split that fills the last round of workgroups best
   const int cus = ef_num_cus();
   int ichunks = 1;
@@ -679,7 +671,8 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
                   work_counter, node_off, graph_order};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
-  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;
+  if (!(E12 ? MBVAE_ALLOW_BIG_LDS(edge_fused_fwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_fused_fwd_kernel<false>)))
+    return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
@@ -694,14 +687,13 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
                        hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0) return MBVAE_EINVAL;
-  if (d != 64 || dff != 128 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  if (d != 64 || dff != 128 || M > 0x7fffffff || mbvae_opt(MBVAE_OPT_NO_EDGE_FFN)) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {x, W1, W2, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
   EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid};
   const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
-  if (hipFuncSetAttribute((const void*)edge_ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return MBVAE_ELAUNCH;
+  if (!MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel)) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
   hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
@@ -716,14 +708,13 @@ int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const 
                           int64_t de, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (M <= 0 || (mask && n <= 0)) return MBVAE_EINVAL;
-  if (dx != 256 || de != 64 || M > 0x7fffffff || getenv("MBVAE_NO_EDGE_FFN")) return MBVAE_EUNSUPPORTED;
+  if (dx != 256 || de != 64 || M > 0x7fffffff || mbvae_opt(MBVAE_OPT_NO_EDGE_FFN)) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {P, W, E, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
   EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid, uniform_padding};
   const size_t smem = sizeof(float) * (64 * 257 + 3 * 64 + 8 * 64);
-  if (hipFuncSetAttribute((const void*)edge_out_ln_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return MBVAE_ELAUNCH;
+  if (!MBVAE_ALLOW_BIG_LDS(edge_out_ln_fwd_kernel)) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
   hipLaunchKernelGGL(edge_out_ln_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();

@@ -18,6 +18,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Streaming operand load for kernels whose wave-wide access covers whole cache lines that nobody touches again
@@ -50,7 +51,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int r
   if (g.bias) v += g.bias[col];
   if (g.act == 1) v = fmaxf(v, 0.f);
   if (g.drop_p > 0.f) v *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
-  v *= keep_row;
+  v = keep_row != 0.f ? v : 0.f;      // a select: a masked row may hold non-finite values
   if (g.accumulate) v += g.C[(int64_t)row * g.ldc + col];
   return v;
 }
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int q = 0; q < 4; ++q) {
           float v = ra[p * 4 + q];
           if (has_gate && !(rg[p * 4 + q] > 0.f)) v = 0.f;
-          if (prologue) v *= keep;
+          if (prologue) v = keep != 0.f ? v * keep : 0.f;      // select: masked rows may hold non-finite values
           As[((tid & 7) * 4 + q) * LDAS + (tid >> 3) + 32 * p] = v;
         }
       }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int q = 0; q < 4; ++q) {
           v[q] = ra[p * 4 + q];
           if (has_gate && !(rg[p * 4 + q] > 0.f)) v[q] = 0.f;
-          if (prologue) v[q] *= keep;
+          if (prologue) v[q] = keep != 0.f ? v[q] * keep : 0.f;
         }
         *reinterpret_cast<float4*>(&As[(tid / (BM / 4) + ROWS_PER_PASS * p) * LDAS + (tid % (BM / 4)) * 4]) =
             make_float4(v[0], v[1], v[2], v[3]);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           float o = acc[i][j][v] + bj[j];
           if (g.act == 1) o = fmaxf(o, 0.f);
           if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
-          o *= keep[v];
+          o = keep[v] != 0.f ? o : 0.f;
           if (g.accumulate) o += g.C[(int64_t)row * g.ldc + col];
           g.C[(int64_t)row * g.ldc + col] = o;
         }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
       for (int q = 0; q < 4; ++q) {
         float v = ra[p * 4 + q];
         if (GATE && !(rg[p * 4 + q] > 0.f)) v = 0.f;
-        if (prologue) v *= rk;
+        if (prologue) v = rk != 0.f ? v * rk : 0.f;
         dst[((tid & 7) * 4 + q) * LDA + (tid >> 3) + 64 * p] = v;
       }
     }
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
             float o = acc[i][j][v] + bj[j];
             if (g.act == 1) o = fmaxf(o, 0.f);
             if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
-            o *= keep[v];
+            o = keep[v] != 0.f ? o : 0.f;
             if (g.accumulate) o += g.C[(int64_t)row * g.ldc + col];
             g.C[(int64_t)row * g.ldc + col] = o;
             acc[i][j][v] = 0.f;
@@ -549,7 +550,9 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
           if (!(rg[S][p].z > 0.f)) v.z = 0.f;                                                          \
           if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                          \
         }                                                                                              \
-        v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                    \
+        /* selects: a masked row may hold non-finite values */                                         \
+        v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                            \
+        v.z = rk != 0.f ? v.z * rk : 0.f; v.w = rk != 0.f ? v.w * rk : 0.f;                            \
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                    \
         ra[S][p] = v;                                                                                  \
       }                                                                                                \
@@ -657,24 +660,16 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
 #undef TS2_ST
 }
 
-static int ts_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
-  return cus;
-}
+static int ts_num_cus() { return mbvae_num_cus(); }
 
 // returns MBVAE_EUNSUPPORTED when the shape does not qualify (the caller then uses the generic kernel)
 template <bool B_KC>
 static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
-  if (getenv("MBVAE_NO_TSGEMM")) return MBVAE_EUNSUPPORTED;
+  if (mbvae_opt(MBVAE_OPT_NO_TSGEMM)) return MBVAE_EUNSUPPORTED;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0;
   if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
-  if (!getenv("MBVAE_NO_TSGEMM2") && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
+  if (!mbvae_opt(MBVAE_OPT_NO_TSGEMM2) && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
       !(g.addend && g.drop_p > 0.f) && (int64_t)g.M * g.ldc < 0x3fffffff) {
     const size_t smem2 = sizeof(float) * (size_t)g.K * (g.N + 1);
     const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
@@ -685,13 +680,19 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     if (wide) k = tsgemm2_kernel<4, B_KC, false, 8>;
     else if (g.addend) k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8, true> : tsgemm2_kernel<2, B_KC, false, 8, true>;
     else k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8> : tsgemm2_kernel<2, B_KC, false, 8>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess) return MBVAE_ELAUNCH;
+    bool lds_ok;
+    if (wide) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<4, B_KC, false, 8>));
+    else if (g.addend && g.a_gate) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, true, 8, true>));
+    else if (g.addend) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, false, 8, true>));
+    else if (g.a_gate) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, true, 8>));
+    else lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, false, 8>));
+    if (!lds_ok || smem2 > MBVAE_LDS_LIMIT) return MBVAE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
     return mbvae_launch_status();
   }
   if (g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
-  if (g.N != 128 && g.N != 256 && !(g.N == 64 && getenv("MBVAE_TSGEMM_N64"))) return MBVAE_EUNSUPPORTED;
+  if (g.N != 128 && g.N != 256 && !(g.N == 64 && mbvae_opt(MBVAE_OPT_TSGEMM_N64))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
   if (g.M % BM) return MBVAE_EUNSUPPORTED;
   const size_t smem = sizeof(float) * ((size_t)g.K * (g.N + 1) + 2 * 32 * (BM + 1) + 2 * BM);
@@ -702,8 +703,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     auto kg = tsgemm_kernel<n, bm, wm, wn, B_KC, true>;                                                               \
     auto kn = tsgemm_kernel<n, bm, wm, wn, B_KC, false>;                                                              \
     auto k = gate ? kg : kn;                                                                                          \
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
-      return MBVAE_ELAUNCH;                                                                                           \
+    if (!(gate ? MBVAE_ALLOW_BIG_LDS(kg) : MBVAE_ALLOW_BIG_LDS(kn)) || smem > MBVAE_LDS_LIMIT) return MBVAE_ELAUNCH;  \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g);                                                    \
   } while (0)
   if (g.N == 256) TS_LAUNCH(256, 128, 2, 4);
@@ -788,7 +788,8 @@ __global__ __launch_bounds__(512) void tswgrad_kernel(GemmArgs g, int nchunks) {
         if (!(rg[S][p].w > 0.f)) v.w = 0.f;                                                            \
       }                                                                                                \
       const float rk = mbvae_mask_keep(g.a_mask_mode, ma[S][p], mb[S][p]) ? vld[S] : 0.f;              \
-      v.x *= rk; v.y *= rk; v.z *= rk; v.w *= rk;                                                      \
+      v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                              \
+      v.z = rk != 0.f ? v.z * rk : 0.f; v.w = rk != 0.f ? v.w * rk : 0.f;                              \
       cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;                                              \
       *reinterpret_cast<float4*>(da + (arow + RGA * p) * LDA + ac4) = v;                               \
     }                                                                                                  \
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(512) void tswgrad2_kernel(GemmArgs g, int nchunks) 
           if (!(rg[S][s].y > 0.f)) v.y = 0.f;                                                          \
         }                                                                                              \
         const float rk = ((kbits >> (2 * s)) & 1u) ? sc : 0.f;                                         \
-        v.x *= rk; v.y *= rk;                                                                          \
+        v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                            \
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
         cs0 += v.x; cs1 += v.y;                                                                        \
         ra[S][s] = v; rb[S][s] = b;                                                                    \
@@ -1015,14 +1016,14 @@ __global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int spl
 
 // returns MBVAE_EUNSUPPORTED when the shape does not qualify (the caller then uses the generic kernel)
 static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
-  if (getenv("MBVAE_NO_TSWGRAD")) return MBVAE_EUNSUPPORTED;
+  if (mbvae_opt(MBVAE_OPT_NO_TSWGRAD)) return MBVAE_EUNSUPPORTED;
   const int P = g.M, Q = g.N, R = g.K;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
   if (!aligned || R < 32768 || R % 32 || P * Q > 32768 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
     return MBVAE_EUNSUPPORTED;
   if (P * Q > 16384 && !(P == 512 && Q == 64 && !g.a_gate)) return MBVAE_EUNSUPPORTED;
   // the widest edge-path gradient (fused e_mul|e_add projection, 512 x 64) runs on the LDS-free kernel: 8 % faster there
-  if (!getenv("MBVAE_NO_TSWGRAD2") && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P == 512 && Q == 64 && !g.a_gate &&
+  if (!mbvae_opt(MBVAE_OPT_NO_TSWGRAD2) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P == 512 && Q == 64 && !g.a_gate &&
       (int64_t)2 * g.lda + P < 0x7fffffff) {
     const int nchunks2 = R / 64;
     const int grid2 = std::min(nchunks2, ts_num_cus());
@@ -1051,13 +1052,12 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
     auto kg = tswgrad_kernel<p, q, wm, wn, true>;                                                                     \
     auto kn = tswgrad_kernel<p, q, wm, wn, false>;                                                                    \
     auto k = gate ? kg : kn;                                                                                          \
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
-      return MBVAE_ELAUNCH;                                                                                           \
+    if (!(gate ? MBVAE_ALLOW_BIG_LDS(kg) : MBVAE_ALLOW_BIG_LDS(kn)) || smem > MBVAE_LDS_LIMIT) return MBVAE_ELAUNCH;  \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g, nchunks);                                           \
   } while (0)
   if (P == 512 && Q == 64) {                       // fused e_mul|e_add projection: 64 accumulator registers per lane
     auto k = tswgrad_kernel<512, 64, 8, 1, false>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MBVAE_ELAUNCH;
+    if (!MBVAE_ALLOW_BIG_LDS((tswgrad_kernel<512, 64, 8, 1, false>))) return MBVAE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, g, nchunks);
   }
   else if (P == 256 && Q == 64) TW_LAUNCH(256, 64, 4, 2);
@@ -1090,11 +1090,8 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   else { BM = 128; BN = 128; }
   // fewer than two big tiles per CU leave the chip under-filled and every block latency bound: use small tiles
   if (BM == 128 && (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) < 2 * ts_num_cus()) { BM = 64; BN = 64; }
-  if (const char* force = getenv("MBVAE_GEMM_TILE")) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128
-    if (*force) {
-      const int f = atoi(force);
-      BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
-    }
+  if (const int f = mbvae_opt(MBVAE_OPT_GEMM_TILE); f >= 0) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128
+    BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
   }
   const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
@@ -1140,6 +1137,25 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
 }
 
 extern "C" {
+
+// Process-wide tuning switch `name` (without the MBVAE_ prefix, e.g. "NO_EDGE_FUSED"); see MbvaeOption.
+int mbvae_set_option(const char* name, int value) {
+  if (!name) return MBVAE_EINVAL;
+  for (int i = 0; i < MBVAE_OPT_COUNT; ++i)
+    if (strcmp(name, mbvae_option_names()[i]) == 0) {
+      mbvae_options().v[i].store(value, std::memory_order_relaxed);
+      return MBVAE_OK;
+    }
+  return MBVAE_EINVAL;
+}
+
+// Current value of a tuning switch, or MBVAE_EINVAL (-1) for an unknown name (GEMM_TILE's "automatic" is also -1).
+int mbvae_get_option(const char* name) {
+  if (!name) return MBVAE_EINVAL;
+  for (int i = 0; i < MBVAE_OPT_COUNT; ++i)
+    if (strcmp(name, mbvae_option_names()[i]) == 0) return mbvae_opt(i);
+  return MBVAE_EINVAL;
+}
 
 // y[M,N] = mask_rows( dropout( act( x[M,K] @ w[N,K]^T + bias ) ) )  (+= y if accumulate)
 int mbvae_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,

@@ -571,8 +571,7 @@ int mbvae_pool_stats_fwd(const float* x, float* stats, int32_t* arg, int64_t bs,
   const dim3 grid((unsigned)((D + 255) / 256), (unsigned)bs);
   if (L >= 2048) {
     const size_t smem = (size_t)1024 * 4 * 7 * sizeof(float);
-    if (hipFuncSetAttribute((const void*)pool_fwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return MBVAE_ELAUNCH;
+    if (!MBVAE_ALLOW_BIG_LDS(pool_fwd_kernel<1024>)) return MBVAE_ELAUNCH;
     hipLaunchKernelGGL(pool_fwd_kernel<1024>, grid, dim3(1024), smem, stream, x, stats, (int*)arg, (int)L, (int)D);
   } else {
     const size_t smem = (size_t)512 * 4 * 7 * sizeof(float);
@@ -660,8 +659,7 @@ int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask
   if (!x || !stats || !mask || !row_idx || !nvalid || bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (D != 64 || n > 1024 || bs > 0x7fffffff || bs * n * n > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   const size_t smem = (size_t)1024 * 4 * 5 * sizeof(float);
-  if (hipFuncSetAttribute((const void*)pool_pairs_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return MBVAE_ELAUNCH;
+  if (!MBVAE_ALLOW_BIG_LDS(pool_pairs_fwd_kernel)) return MBVAE_ELAUNCH;
   hipLaunchKernelGGL(pool_pairs_fwd_kernel, dim3((unsigned)bs), dim3(1024), smem, stream, x, stats, mask, row_idx, nvalid,
                      (int)n, bs * n * n);
   return mbvae_launch_status();

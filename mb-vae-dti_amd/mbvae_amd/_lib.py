@@ -5,7 +5,7 @@ entry point returns a non-zero status, a RuntimeError is raised.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MBVAE_LIB selects another build of the same library (kernel A/B timing); the default is the in-tree build.
@@ -15,6 +15,8 @@ _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 
 # name -> argtypes (restype is int unless listed in _RET64)
 SIGNATURES = {
+    "mbvae_set_option": [c_char_p, _I],
+    "mbvae_get_option": [c_char_p],
     "mbvae_linear_fwd": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P, _I, _I, _F, _U, _I, _P, _L, _P],
     "mbvae_linear_bwd_input": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
     "mbvae_linear_bwd_input_add": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _P],
@@ -93,6 +95,25 @@ def call(name, *args, tag=None, allow_unsupported=False):
     if st != 0:
         raise RuntimeError(f"{name} failed: {_STATUS.get(st, st)}")
     return True
+
+
+class option:
+    """Context manager: `with option("NO_EDGE_FUSED", 1): ...` flips a process-wide tuning switch of the library
+    (mbvae_set_option) and restores the previous value on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        lib = load()
+        self.old = lib.mbvae_get_option(self.name)
+        if lib.mbvae_set_option(self.name, self.value) != 0:
+            raise ValueError(f"unknown option {self.name!r}")
+        return self
+
+    def __exit__(self, *exc):
+        load().mbvae_set_option(self.name, self.old)
+        return False
 
 
 def query(name, *args):

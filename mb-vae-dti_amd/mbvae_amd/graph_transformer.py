@@ -107,8 +107,8 @@ class NodeEdgeBlock(nn.Module):
                                              tile_map=tile_map, order=order,
                                              uniform_padding=tile_map is not None or order is not None)
         else:
-            if not P.requires_grad and not torch.is_grad_enabled():
-                ops.zero_masked_pairs_(P, node_mask)      # the no-gradient attention forward skips padding pairs
+            if not P.requires_grad:         # exactly when the no-gradient attention forward ran: it skips padding pairs
+                ops.zero_masked_pairs_(P, node_mask)
             newE = _lin(self.e_out, P, **edge)
         if pack is not None:
             film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
@@ -210,9 +210,12 @@ class GraphTransformer(nn.Module):
             # (never while a HIP graph is being captured: building the node pack synchronises with the host)
             if (hit["order"] is None and self._fused_edge_widths and os.environ.get("MBVAE_NO_ROW_ORDER") is None
                     and not torch.cuda.is_current_stream_capturing()):
-                hit["order"] = ops.edge_row_order(node_mask, sparse=True)
-                # (packed node rows go through the fused attention kernel, which takes at most 64 nodes per graph)
-                if hit["order"] is not None and node_mask.shape[1] <= 64 and os.environ.get("MBVAE_NO_NODE_PACK") is None:
+                # The sparse form leaves most padding rows of the edge tensor unwritten; only the fused attention
+                # kernel (at most 64 nodes per graph) knows to skip them.  Larger graphs take the dense order, which
+                # writes every row.
+                fused_attention = node_mask.shape[1] <= 64
+                hit["order"] = ops.edge_row_order(node_mask, sparse=fused_attention)
+                if hit["order"] is not None and fused_attention and os.environ.get("MBVAE_NO_NODE_PACK") is None:
                     hit["pack"] = ops.NodePack.build(node_mask)      # (one host synchronisation)
                     if hit["pack"] is not None:                      # the valid pair rows, for the edge in / out MLPs
                         hit["pack"].pair_rows = hit["order"].idx[:int(hit["order"].nvalid[0])].long()

@@ -108,11 +108,14 @@ class _Linear(torch.autograd.Function):
                 if dres is not None:
                     dx += dres
             dx = dx.reshape(xshape)
-        if ctx.needs_input_grad[1]:
+        need_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_db:     # (a frozen weight with a trainable bias still needs the column sums)
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            db = torch.empty((N,), dtype=torch.float32, device=dy.device) if has_bias else None
+            db = torch.empty((N,), dtype=torch.float32, device=dy.device) if need_db else None
             _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
                       _ptr(gate), gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+            if not ctx.needs_input_grad[1]:
+                dw = None
         return dx, dw, db, None, None, None, None, None, None, None
 
 

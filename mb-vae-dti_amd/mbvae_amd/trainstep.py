@@ -51,12 +51,17 @@ class DenoiserTrainStep:
         self.me = torch.tensor(ME, device=self.device)
         self.graph_feats = ExtraFeatures(max_n_nodes=64)
         self.mol_feats = ExtraMolecularFeatures(VALENCIES, 1000.0, ATOM_WEIGHTS)
-        self.sync = BucketedGradSync(self.model.parameters()) if distributed else None
+        # the denoiser's autograd graph is the same every step: the set of parameters without gradient (the global
+        # output head when only node / edge logits enter the loss) is agreed on once
+        self.sync = BucketedGradSync(self.model.parameters(), static_graph=True) if distributed else None
         # same update rule as the reference's AdamW(amsgrad=True); `fused` runs it as one multi-tensor kernel per
         # dtype/device group instead of ~10 element-wise passes over the 73 M parameters
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=True,
                                      fused=True)
         self.last = {}
+        # identical weights everywhere, but every rank draws its own timesteps, noise and dropout seeds
+        rank = torch.distributed.get_rank() if (distributed and torch.distributed.is_initialized()) else 0
+        torch.manual_seed(seed + 1 + rank)
 
     def step(self, X0, E0, mask, cond):
         bs, n, cx = X0.shape

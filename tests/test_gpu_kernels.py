@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from mbvae_amd import _lib
 from tests._util import assert_close, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -735,8 +736,8 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
     P0, wV0, _, _ = run(False)        # inference: no projection output is written at all, P only on valid pairs
     pm = (mask.unsqueeze(1) & mask.unsqueeze(2)).cuda()
     assert torch.equal(P0[pm], P[pm]) and torch.equal(wV0 * xm.cuda(), wV * xm.cuda())
-    monkeypatch.setenv("MBVAE_NO_EDGE_FUSED", "1")   # the two separate forward kernels
-    P1, wV1, stats1, grads1 = run(True)
+    with _lib.option("NO_EDGE_FUSED", 1):            # the two separate forward kernels
+        P1, wV1, stats1, grads1 = run(True)
     assert_close(P1, P, rtol=2e-6, what="P fused vs separate"); assert_close(wV1 * xm.cuda(), wV * xm.cuda(), rtol=2e-6, what="wV fused vs separate")
     for a, b_ in zip(grads1, grads):
         assert_close(a, b_, rtol=1e-5, what="grads fused vs separate")
@@ -819,8 +820,8 @@ def test_edge_ffn_inference_fused(ops, rows, monkeypatch):
         assert bool((canvas[~written.cuda()] == 7.0).all()), "the sparse order wrote padding rows beyond its first padding tile"
         skip0 = ops.ffn_ln_inference(xp[:64].contiguous().fill_(0.25), *dv[1:], 1e-5, tile_map=torch.zeros(2, dtype=torch.uint8).cuda())
         assert torch.equal(skip0, ops.ffn_ln_inference(torch.full((64, 64), 0.25).cuda(), *dv[1:], 1e-5))
-    monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
-    sep = ops.ffn_ln_inference(*dv, 1e-5)
+    with _lib.option("NO_EDGE_FFN", 1):
+        sep = ops.ffn_ln_inference(*dv, 1e-5)
     assert_close(sep, ref, what="separate kernels")
     assert_close(got, sep, rtol=3e-6, what="fused vs separate")
 
@@ -875,9 +876,9 @@ def test_edge_out_ln_inference_fused(ops, bs, n, sizes, monkeypatch):
             dense = ops.pool_stats(base)
             ragged = ops.pool_stats_pairs(gs, sp)
             assert_close(ragged, dense, rtol=1e-5, what="pair pooling with analytic padding")
-    monkeypatch.setenv("MBVAE_NO_EDGE_FFN", "1")
-    sep = ops.edge_out_ln_inference(*args)
-    sep2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:])
+    with _lib.option("NO_EDGE_FFN", 1):
+        sep = ops.edge_out_ln_inference(*args)
+        sep2 = ops.edge_out_ln_inference(Pn.cuda(), *args[1:])
     assert torch.equal(sep2, sep), "separate kernels: masked pairs of P leaked into the result"
     assert_close(sep, ref, what="separate kernels")
     assert_close(got, sep, rtol=3e-6, what="fused vs separate")

@@ -100,65 +100,94 @@ def _free_port():
     return p
 
 
+def _toy_net():
+    """Denoiser-shaped toy: a trunk, a head that enters the loss and a head that does not (the denoiser's global
+    output MLP when only node / edge logits are scored)."""
+    torch.manual_seed(0)
+    return torch.nn.ModuleDict({"trunk": torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU()),
+                                "head": torch.nn.Linear(8, 1), "unused_head": torch.nn.Linear(8, 4)})
+
+
+def _toy_loss(net, x):
+    return net["head"](net["trunk"](x)).pow(2).mean()
+
+
 def _ddp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mbvae_amd.ddp import BucketedGradSync
-    torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
-    sync = BucketedGradSync(net.parameters(), bucket_bytes=1024)       # several buckets
-    assert len(sync.buckets) > 1
     g = torch.Generator().manual_seed(100)
     data = torch.randn(world, 6, 16, generator=g)
-    for step in range(2):                                               # second step checks zero_grad / hook re-arming
-        net(data[rank] * (step + 1)).pow(2).mean().backward()
-        sync.finish()
-        grads = torch.cat([p.grad.reshape(-1).clone() for p in net.parameters()])
-        if step == 0:
+    result = {}
+    for static in (False, True):
+        net = _toy_net()
+        sync = BucketedGradSync(net.parameters(), bucket_bytes=1024, static_graph=static)       # several buckets
+        assert len(sync.buckets) > 1
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.1, amsgrad=True)
+        launched_in_hooks = []
+        for step in range(3):                                             # later steps check zero_grad / hook re-arming
+            _toy_loss(net, data[rank] * (step + 1)).backward()
+            launched_in_hooks.append(sync._next)
+            sync.finish()
+            # parameters outside the loss end the step WITHOUT a gradient, as in a single process
+            assert all(p.grad is None for p in net["unused_head"].parameters())
+            grads = torch.cat([p.grad.reshape(-1).clone() for p in net.parameters() if p.grad is not None])
+            opt.step()
             sync.zero_grad()
-    # a parameter that takes no part in the loss (the denoiser's global-feature output head in the graph-only loss):
-    # its bucket never fills during backward and must still be reduced by finish()
-    torch.manual_seed(1)
-    used, unused = torch.nn.Linear(16, 4), torch.nn.Linear(16, 4)
-    sync2 = BucketedGradSync(list(used.parameters()) + list(unused.parameters()), bucket_bytes=1 << 20)   # ONE bucket
-    assert len(sync2.buckets) == 1
-    for step in range(2):
-        used(data[rank] * (step + 1)).pow(2).mean().backward()
-        sync2.finish()
-        g2 = torch.cat([p.grad.reshape(-1).clone() for p in used.parameters()])
-        assert all(float(p.grad.abs().max()) == 0.0 for p in unused.parameters())
-        sync2.zero_grad()
+        if static:       # the used set is known after step 0: the bucket holding the unused head no longer blocks the hooks
+            assert launched_in_hooks[0] == 0 and launched_in_hooks[2] == len(sync.buckets), launched_in_hooks
+        else:            # bucket 0 holds the unused head (reverse registration order): everything waits for finish()
+            assert launched_in_hooks == [0, 0, 0], launched_in_hooks
+        result[f"grads_{int(static)}"] = grads
+        result[f"weights_{int(static)}"] = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    # a parameter used on ONE rank only: the other ranks contribute zeros, nobody drops it, the order of collectives
+    # stays 0, 1, 2, ... on both ranks
+    net = _toy_net()
+    sync = BucketedGradSync(net.parameters(), bucket_bytes=1024)
+    loss = _toy_loss(net, data[rank])
+    if rank == 1:
+        loss = loss + net["unused_head"](net["trunk"](data[rank])).pow(2).mean()
+    loss.backward()
+    sync.finish()
+    assert all(p.grad is not None for p in net["unused_head"].parameters())
+    result["one_rank_only"] = torch.cat([p.grad.reshape(-1).clone() for p in net["unused_head"].parameters()])
     if rank == 0:
-        torch.save({"grads": grads, "partial": g2}, out)
+        torch.save(result, out)
     dist.destroy_process_group()
 
 
 def test_bucketed_grad_sync_gloo_world2(tmp_path):
+    """Two ranks with BucketedGradSync == one process that averages the two shards' gradients: same gradients, same
+    weights after three AdamW(amsgrad, weight decay) steps, unused parameters untouched."""
     out = str(tmp_path / "g.pt")
     port = _free_port()
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
     saved = torch.load(out, weights_only=True)
-    got = saved["grads"]
-    torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
     g = torch.Generator().manual_seed(100)
     data = torch.randn(2, 6, 16, generator=g)
-    tot = None
-    for r in range(2):
-        net.zero_grad()
-        net(data[r] * 2).pow(2).mean().backward()
-        v = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-        tot = v if tot is None else tot + v
-    assert torch.allclose(got, tot / 2, rtol=1e-6, atol=1e-7)
-    torch.manual_seed(1)
-    used = torch.nn.Linear(16, 4)
-    tot = None
-    for r in range(2):
-        used.zero_grad()
-        used(data[r] * 2).pow(2).mean().backward()
-        v = torch.cat([p.grad.reshape(-1) for p in used.parameters()])
-        tot = v if tot is None else tot + v
-    assert torch.allclose(saved["partial"], tot / 2, rtol=1e-6, atol=1e-7), "bucket with an unused parameter was not reduced"
+    net = _toy_net()
+    w0_unused = torch.cat([p.detach().reshape(-1).clone() for p in net["unused_head"].parameters()])
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.1, amsgrad=True)
+    for step in range(3):
+        tot = None
+        for r in range(2):
+            net.zero_grad(set_to_none=True)
+            _toy_loss(net, data[r] * (step + 1)).backward()
+            v = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+            tot = v if tot is None else [a if b is None else a + b for a, b in zip(tot, v)]
+        for p, gsum in zip(net.parameters(), tot):
+            p.grad = None if gsum is None else gsum / 2
+        want_grads = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
+        opt.step()
+    want_w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in net["unused_head"].parameters()]), w0_unused)   # no decay
+    for k in ("0", "1"):
+        assert torch.allclose(saved["grads_" + k], want_grads, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(saved["weights_" + k], want_w, rtol=1e-6, atol=1e-7), "post-step weights differ from dp1"
+    net = _toy_net()
+    net["unused_head"](net["trunk"](data[1])).pow(2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net["unused_head"].parameters()]) / 2
+    assert torch.allclose(saved["one_rank_only"], want, rtol=1e-6, atol=1e-7)
 
 
 class _FakeSampler(torch.nn.Module):
