@@ -109,13 +109,17 @@ def sample_discrete_features(probX, probE, node_mask, generator=None):
     return PlaceHolder(X=X, E=E + E.transpose(1, 2), y=torch.zeros(bs, 0, device=probX.device).long())
 
 
-def sample_discrete_feature_noise(limit_dist, node_mask, generator=None):
-    """z_T ~ limit distribution as masked one-hot floats (diffusion/utils.py:284-317)."""
+def sample_discrete_feature_noise(limit_dist, node_mask, generator=None, exp=None):
+    """z_T ~ limit distribution as masked one-hot floats (diffusion/utils.py:284-317).  exp = (expX [bs*n,cx],
+    expE [bs*n*n,ce]): Exp(1) draws to use instead of the generator's."""
     bs, n = node_mask.shape
     dev = node_mask.device
     mx, me = limit_dist.X.to(dev).float(), limit_dist.E.to(dev).float()
-    eX = exp_draws(bs * n, mx.numel(), dev, generator)
-    eE = exp_draws(bs * n * n, me.numel(), dev, generator)
+    if exp is not None:
+        eX, eE = exp[0].to(dev), exp[1].to(dev)
+    else:
+        eX = exp_draws(bs * n, mx.numel(), dev, generator)
+        eE = exp_draws(bs * n * n, me.numel(), dev, generator)
     # forward noising with abar = 0 from any clean graph IS the limit distribution: reuse the kernel
     X0 = torch.zeros(bs, n, mx.numel(), device=dev); X0[..., 0] = 1
     E0 = torch.zeros(bs, n, n, me.numel(), device=dev); E0[..., 0] = 1

@@ -38,7 +38,10 @@ class ExtraFeatures:
     def __init__(self, max_n_nodes=64):
         self.max_n_nodes = max_n_nodes
 
-    def __call__(self, E_t, node_mask, lcc_noise=None):
+    def __call__(self, E_t, node_mask, lcc_noise=None, eigvec=None):
+        """eigvec [bs,n,2] (optional) replaces the two eigenvector features: eigenvectors are only defined up to sign
+        (and up to a rotation inside a degenerate eigenspace), so a replay of another implementation's step must use
+        that implementation's choice."""
         bs, n = node_mask.shape
         m = node_mask.float()
         A_raw = E_t[..., 1:].sum(-1).float()
@@ -66,6 +69,9 @@ class ExtraFeatures:
         V_ext = torch.cat((V, torch.zeros(bs, n, k_vec, device=V.device)), 2)
         idx = (torch.arange(k_vec, device=V.device)[None, None, :] + ncc[:, None, None]).expand(-1, n, -1)
         vecs = torch.gather(V_ext, 2, idx) * m.unsqueeze(2)
+        self.last_eigvec = vecs
+        if eigvec is not None:
+            vecs = eigvec.to(vecs)
 
         X_extra = torch.cat((xc, not_lcc, vecs), -1)
         y_extra = torch.cat((m.sum(1, keepdim=True) / self.max_n_nodes, yc, ncc.unsqueeze(-1).float(), vals), 1)

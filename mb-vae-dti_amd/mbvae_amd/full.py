@@ -7,15 +7,14 @@ is importable and a small nn.Module stand-in otherwise.  The reference's host-sy
 RDKit molecule building is used only if RDKit is importable (sample_batch then returns Mol objects, otherwise the
 (atom classes, bond classes) tensors).
 """
-import inspect
 import logging
-from pathlib import Path
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .abstract import ACTIVATIONS, AbstractDTIModel, encode_no_edge, to_dense  # noqa: F401  (re-exported)
 from .blocks import AttentiveAggregator, ConcatAggregator, CrossAttentionFusion, ResidualEncoder, TransformerEncoder
 from .containers import BatchData, EmbeddingData, GraphData, LossData, PlaceHolder, PredictionData
 from .diffusion import (DistributionNodes, MarginalUniformTransition, PredefinedNoiseScheduleDiscrete, exp_draws,
@@ -25,70 +24,6 @@ from .graph_transformer import GraphTransformer
 from .heads import DTIHead, InfoNCEHead, KLVariationalHead, ReconstructionHead
 
 logger = logging.getLogger(__name__)
-
-try:  # pragma: no cover - depends on the environment
-    import pytorch_lightning as pl
-    _Base = pl.LightningModule
-except Exception:  # noqa: BLE001
-    class _AttrDict(dict):
-        __getattr__ = dict.__getitem__
-        __setattr__ = dict.__setitem__
-
-    class _Base(nn.Module):
-        """Minimal LightningModule surface: hparams, device, log(), trainer."""
-
-        def __init__(self):
-            super().__init__()
-            self.hparams = _AttrDict()
-            self.trainer = None
-
-        def save_hyperparameters(self):
-            frame = inspect.currentframe().f_back
-            info = inspect.getargvalues(frame)
-            for name in info.args:
-                if name != "self":
-                    self.hparams[name] = info.locals[name]
-
-        @property
-        def device(self):
-            p = next(self.parameters(), None)
-            return p.device if p is not None else torch.device("cpu")
-
-        def log(self, *args, **kwargs):
-            pass
-
-
-ACTIVATIONS = {"relu": nn.ReLU, "gelu": nn.GELU, "elu": nn.ELU, "leaky_relu": nn.LeakyReLU, "selu": nn.SELU, "swish": nn.SiLU,
-               "silu": nn.SiLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "mish": nn.Mish, "glu": nn.GLU}
-
-
-# ------------------------------------------------------------------------------------------------ dense batches
-def encode_no_edge(E):
-    """Prepend the 'no bond' class (1 where no bond type is set) and clear the diagonal (diffusion/utils.py:102-120)."""
-    none = (E.sum(dim=3, keepdim=True) == 0).to(E.dtype)
-    out = torch.cat((none, E), dim=3)
-    n = E.shape[1]
-    out[:, torch.arange(n), torch.arange(n)] = 0
-    return out
-
-
-def to_dense(x, edge_index, edge_attr, batch):
-    """Sparse (PyG-style) batch -> dense X [bs,n,cx], E [bs,n,n,1+bond types], node_mask [bs,n]; self loops dropped.
-    Follows to_dense_batch / to_dense_adj semantics (duplicate edges add up).  X and E are NOT masked."""
-    bs = int(batch.max().item()) + 1 if batch.numel() else 0
-    counts = torch.bincount(batch, minlength=bs)
-    n = int(counts.max().item()) if bs else 0
-    start = torch.cumsum(counts, 0) - counts
-    pos = torch.arange(batch.numel(), device=batch.device) - start[batch]
-    X = x.new_zeros(bs, n, x.shape[-1])
-    X[batch, pos] = x
-    node_mask = torch.zeros(bs, n, dtype=torch.bool, device=x.device)
-    node_mask[batch, pos] = True
-    keep = edge_index[0] != edge_index[1]
-    src, dst, attr = edge_index[0][keep], edge_index[1][keep], edge_attr[keep]
-    E = attr.new_zeros(bs, n, n, attr.shape[-1])
-    E.index_put_((batch[src], pos[src], pos[dst]), attr, accumulate=True)
-    return PlaceHolder(X=X, E=encode_no_edge(E), y=None), node_mask
 
 
 # ------------------------------------------------------------------------------------------------ running metrics
@@ -176,7 +111,7 @@ def _posterior(M, M_t, Qt, Qsb, Qtb):
     return num / den.unsqueeze(-1)
 
 
-class FullDTIModel(_Base):
+class FullDTIModel(AbstractDTIModel):
     def __init__(self, phase, finetune_score, learning_rate, weight_decay, scheduler, weights, dti_weights, diff_weights,
                  contrastive_temp, drug_features, target_features, embedding_dim, hidden_dim, factor, n_layers, activation,
                  dropout, bias, encoder_type, aggregator_type, diffusion_steps, sample_every_val, val_samples_per_embedding,
@@ -189,9 +124,13 @@ class FullDTIModel(_Base):
         self.attentive = aggregator_type == "attentive"
         self.weights, self.dti_weights, self.diff_weights = weights, dti_weights, diff_weights
         self.contrastive_temp = contrastive_temp
-        self.train_metrics = self.val_metrics = self.test_metrics = None     # DTI metric collections are out of scope
-        # Optional dict of pre-drawn random tensors {"t_int", "expX", "expE", "lcc_noise", "eps"} consumed instead of the
-        # device generator: lets a step be replayed on exactly the draws another implementation made (parity tests).
+        # Molecule-quality trackers of sampled graphs (RDKit validity / match metrics in the reference): slots for
+        # caller-supplied objects with update(generated_mols=, target_smiles=) / compute() / reset()
+        self.val_mol = self.test_mol = None
+        # Optional dict of pre-drawn random tensors {"t_int", "expX", "expE", "lcc_noise", "eps", "eigvec"} consumed
+        # instead of the device generator: lets a step be replayed on exactly the draws (and the eigenvector gauge)
+        # another implementation made (parity tests).  A value may be a list: the calls then consume it front to back
+        # (a validation step draws its Exp(1) / lcc tensors twice, a sampling run once per reverse step).
         self.replay = None
 
         if phase == "finetune":
@@ -279,105 +218,12 @@ class FullDTIModel(_Base):
                 for p in mod.parameters():
                     p.requires_grad = True
 
-    # ------------------------------------------------------------------ helpers shared with the other model variants
-    @staticmethod
-    def parse_activation(activation):
-        if isinstance(activation, nn.Module):
-            return activation
-        if isinstance(activation, str):
-            if activation.lower() in ACTIVATIONS:
-                return ACTIVATIONS[activation.lower()]()
-            raise ValueError(f"Unknown activation '{activation}'. Available activations: {list(ACTIVATIONS)}")
-        raise TypeError(f"Activation must be either a string or nn.Module, got {type(activation)}")
-
-    def count_trainable_parameters(self):
-        return sum(p.numel() for p in self.parameters() if p.requires_grad)
-
-    def configure_optimizers(self):
-        """AdamW(amsgrad) + {const, step, one_cycle, cosine} exactly as modules/utils.py:109-177."""
-        lr = float(self.hparams.learning_rate)
-        opt = torch.optim.AdamW(self.parameters(), lr=lr, weight_decay=float(self.hparams.weight_decay), amsgrad=True)
-        sched = self.hparams.scheduler
-        if sched == "const" or sched is None:
-            return opt
-        if sched == "step":
-            s = torch.optim.lr_scheduler.StepLR(opt, step_size=30, gamma=0.1)
-        elif sched == "one_cycle":
-            if self.trainer is None:
-                raise ValueError("Trainer must be provided for OneCycleLR scheduler")
-            s = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=self.trainer.estimated_stepping_batches,
-                                                    pct_start=0.3, anneal_strategy="cos")
-            return [opt], [{"scheduler": s, "name": "learning_rate", "interval": "step", "frequency": 1}]
-        elif sched == "cosine":
-            t_max = self.trainer.max_epochs if self.trainer else self.hparams.max_epochs
-            s = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=t_max, eta_min=lr * 0.01)
-        else:
-            raise ValueError(f"Unknown scheduler: {sched}")
-        return {"optimizer": opt, "lr_scheduler": {"scheduler": s, "monitor": "val/loss", "interval": "epoch", "frequency": 1}}
-
-    def load_pretrained_weights(self, checkpoint_path, prefix=None):
-        """Shape-matched, optionally prefix-filtered state_dict merge (modules/utils.py:253-279).  The checkpoint is
-        read with weights_only=True (tensors only)."""
-        checkpoint_path = Path(checkpoint_path)
-        if not checkpoint_path.exists():
-            raise FileNotFoundError(f"Checkpoint not found: {checkpoint_path}")
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        state = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
-        own = self.state_dict()
-        picked = {k: v for k, v in state.items()
-                  if k in own and own[k].shape == v.shape and (prefix is None or k.startswith(prefix))}
-        own.update(picked)
-        self.load_state_dict(own)
-        logger.info("Loaded %d pretrained weights", len(picked))
-
-    def _features_from_batch(self, batch):
-        hp = self.hparams
-        if hp.phase == "pretrain_drug":
-            d, t = [batch["features"][k] for k in hp.drug_features], []
-        elif hp.phase == "pretrain_target":
-            d, t = [], [batch["features"][k] for k in hp.target_features]
-        else:
-            d = [batch["drug"]["features"][k] for k in hp.drug_features]
-            t = [batch["target"]["features"][k] for k in hp.target_features]
-        return (d[0] if len(d) == 1 else d), (t[0] if len(t) == 1 else t)
-
-    def _fingerprints_from_batch(self, batch):
-        if self.hparams.phase == "pretrain_drug":
-            return batch["features"]["FP-Morgan"], None
-        if self.hparams.phase == "pretrain_target":
-            return None, batch["features"]["FP-ESP"]
-        return batch["drug"]["features"]["FP-Morgan"], batch["target"]["features"]["FP-ESP"]
-
-    def _targets_masks_from_batch(self, batch):
-        y = batch["y"]
-        if self.hparams.phase == "finetune":
-            s = self.hparams.finetune_score
-            return y[s].squeeze(-1), y[f"{s}_mask"].squeeze(-1)
-        names = ("Y", "Y_pKd", "Y_KIBA", "Y_pKi")
-        return ({k: y[k].squeeze(-1) for k in names}, {k: y[f"{k}_mask"].squeeze(-1) for k in names[1:]})
-
-    def _extract_graph_data(self, batch):
-        """Dense clean graph from batch['drug']['G'] / batch['G']: any object with x, edge_index, edge_attr, batch
-        (PyG style), a ready GraphData, or {'atom_ids': int8 [bs,n], 'bond_ids': int8 [bs,n,n]} class ids.
-        X and E are not masked; node_mask is returned alongside."""
-        G = batch["drug"]["G"] if "drug" in batch and "G" in batch["drug"] else batch.get("G")
-        if G is None:
-            raise ValueError("No graph data found in batch")
-        if isinstance(G, GraphData):
-            return G
-        if isinstance(G, dict) and "atom_ids" in G:      # compact wire format: int8 class ids, expanded on the device
-            X, E, node_mask = ops.dense_from_ids(G["atom_ids"].to(self.device), G["bond_ids"].to(self.device),
-                                                 len(self.atom_types), self.limit_dist.E.numel())
-            return GraphData(X=X, E=E, node_mask=node_mask)
-        dense, node_mask = to_dense(G.x, G.edge_index, G.edge_attr, G.batch)
-        return GraphData(pyg_batch=G, X=dense.X, E=dense.E, node_mask=node_mask)
-
     def _create_batch_data(self, batch):
         bd = BatchData(raw_batch=batch)
-        bd.drug_features, bd.target_features = self._features_from_batch(batch)
-        bd.drug_fp, bd.target_fp = self._fingerprints_from_batch(batch)
+        bd.drug_features, bd.target_features = self._get_features_from_batch(batch)
+        bd.drug_fp, bd.target_fp = self._get_fingerprints_from_batch(batch)
         if self.phase not in ("pretrain_drug", "pretrain_target"):
-            bd.dti_targets, bd.dti_masks = self._targets_masks_from_batch(batch)
+            bd.dti_targets, bd.dti_masks = self._get_targets_masks_from_batch(batch)
         if self.phase not in ("pretrain_target", "finetune"):
             bd.graph_data = self._extract_graph_data(batch)
             rep = batch.get("representations") if self.hparams.phase == "pretrain_drug" else batch["drug"].get("representations")
@@ -399,8 +245,7 @@ class FullDTIModel(_Base):
 
         if self.phase != "pretrain_target":
             e, emb.drug_attention = encode(self.drug_encoders, self.drug_aggregator, self.hparams.drug_features, drug_features)
-            eps = (self.replay or {}).get("eps")
-            emb.drug_embedding, emb.drug_mu, emb.drug_logvar = self.drug_kl_head(e, None if eps is None else eps.to(e.device))
+            emb.drug_embedding, emb.drug_mu, emb.drug_logvar = self.drug_kl_head(e, self._replayed("eps", e.device))
         if self.phase != "pretrain_drug":
             emb.target_embedding, emb.target_attention = encode(self.target_encoders, self.target_aggregator,
                                                                 self.hparams.target_features, target_features)
@@ -412,6 +257,18 @@ class FullDTIModel(_Base):
         return emb, pred
 
     # ------------------------------------------------------------------ diffusion
+    def _replayed(self, key, device=None):
+        """Next pre-drawn tensor for `key`, or None when the step draws it itself."""
+        rp = self.replay
+        if not rp or key not in rp:
+            return None
+        v = rp[key]
+        if isinstance(v, list):
+            if not v:
+                return None
+            v = v.pop(0)
+        return v if device is None or v is None else v.to(device)
+
     def _marginals(self, device):
         key = str(device)
         cache = self.__dict__.setdefault("_marginal_cache", {})
@@ -425,21 +282,25 @@ class FullDTIModel(_Base):
         bs, n, cx = X.shape
         dev = X.device
         low = 0 if self.training else 1
-        rp = self.replay or {}
-        t_int = rp["t_int"].to(dev).float() if "t_int" in rp else torch.randint(low, self.T + 1, size=(bs, 1), device=dev).float()
+        t_int = self._replayed("t_int", dev)
+        t_int = t_int.float() if t_int is not None else torch.randint(low, self.T + 1, size=(bs, 1), device=dev).float()
         t, s = t_int / self.T, (t_int - 1) / self.T
         beta_t = self.noise_schedule(t_normalized=t)
         a_s = self.noise_schedule.get_alpha_bar(t_normalized=s)
         a_t = self.noise_schedule.get_alpha_bar(t_normalized=t)
         mx, me = self._marginals(dev)
-        eX = rp["expX"].to(dev) if "expX" in rp else exp_draws(bs * n, cx, dev)
-        eE = rp["expE"].to(dev) if "expE" in rp else exp_draws(bs * n * n, E.shape[-1], dev)
+        eX, eE = self._exp_pair(bs, n, cx, E.shape[-1], dev)
         _, _, X_t, E_t = ops.apply_noise(X.float(), E.float(), node_mask, a_t, mx, me, eX, eE)
         return X_t, E_t, {"t_int": t_int, "t": t, "beta_t": beta_t, "alpha_s_bar": a_s, "alpha_t_bar": a_t}
 
+    def _exp_pair(self, bs, n, cx, ce, dev):
+        """Exp(1) draws for one categorical sample of all nodes, then all n*n pairs (the reference's draw order)."""
+        eX, eE = self._replayed("expX", dev), self._replayed("expE", dev)
+        return (eX if eX is not None else exp_draws(bs * n, cx, dev)), (eE if eE is not None else exp_draws(bs * n * n, ce, dev))
+
     def get_extra_features(self, X_t, E_t, noise_params, node_mask):
-        noise = (self.replay or {}).get("lcc_noise")
-        Xg, yg = self.graph_structure_features(E_t, node_mask, lcc_noise=None if noise is None else noise.to(E_t.device))
+        Xg, yg = self.graph_structure_features(E_t, node_mask, lcc_noise=self._replayed("lcc_noise", E_t.device),
+                                               eigvec=self._replayed("eigvec", E_t.device))
         # apply_noise's output is an int64 one-hot in the reference (t_int marks that path): see ExtraMolecularFeatures
         Xm, ym = self.molecular_features(X_t, E_t, truncate_weight="t_int" in noise_params)
         return torch.cat((Xg, Xm), dim=2), torch.cat((yg, ym, noise_params["t"]), dim=1)
@@ -500,7 +361,7 @@ class FullDTIModel(_Base):
         # q(G_0 | G) uses Q_0 = (1 - beta_0) I + beta_0 1 m^T, i.e. the forward kernel with "abar" = 1 - beta_0
         beta_0 = self.noise_schedule(t_normalized=t0)
         mx, me = self._marginals(dev)
-        eX, eE = exp_draws(bs * n, cx, dev), exp_draws(bs * n * n, E.shape[-1], dev)
+        eX, eE = self._exp_pair(bs, n, cx, E.shape[-1], dev)
         Xc, Ec, _, _ = ops.apply_noise(X, E, node_mask, 1 - beta_0, mx, me, eX, eE)
         # the reference one-hot-encodes this sample WITHOUT masking it: padded nodes / pairs carry a sampled class
         X0, E0 = F.one_hot(Xc, cx).float(), F.one_hot(Ec, E.shape[-1]).float()
@@ -605,9 +466,74 @@ class FullDTIModel(_Base):
 
     def test_step(self, batch, batch_idx):
         bd, emb, pred, loss_data = self._common_step(batch, step="test")
+        if self.phase not in ("pretrain_target", "finetune") and bd.graph_data is not None:
+            if not hasattr(self, "_test_embeddings_buffer"):
+                self._test_embeddings_buffer, self._test_smiles_buffer = [], []
+            if len(self._test_embeddings_buffer) < 10:
+                self._test_embeddings_buffer.append(emb.drug_embedding.detach())
+                self._test_smiles_buffer.extend(bd.smiles or [])
         total = loss_data.compute_loss(self.weights)
         self._log_losses("test", loss_data, total)
         return total
+
+    # ------------------------------------------------------------------ epoch ends (full.py:1298-1485 of the reference)
+    def on_train_epoch_end(self):
+        super().on_train_epoch_end()
+        if self.phase not in ("pretrain_target", "finetune"):
+            for key, value in self.train_mol.compute().items():
+                self.log(key, value)
+            self.train_mol.reset()
+
+    def _sample_buffered(self, split, samples_per_embedding):
+        """Conditional sampling from the drug embeddings buffered during the epoch (at most 5 validation / 10 test
+        batches); feeds the optional molecule tracker with the generated groups and the matching SMILES slice.
+        Returns the generated groups per buffered batch and clears the buffers."""
+        emb_buf = getattr(self, f"_{split}_embeddings_buffer", None)
+        if not emb_buf:
+            return []
+        smiles = getattr(self, f"_{split}_smiles_buffer")
+        tracker = getattr(self, f"{split}_mol")
+        out = []
+        for i, emb in enumerate(emb_buf):
+            mols = self.sample_batch(drug_embeddings=emb, num_samples_per_embedding=samples_per_embedding)
+            out.append(mols)
+            if tracker is not None:
+                bs = emb.size(0)
+                tracker.update(generated_mols=mols, target_smiles=smiles[i * bs:(i + 1) * bs])
+        delattr(self, f"_{split}_embeddings_buffer")
+        delattr(self, f"_{split}_smiles_buffer")
+        return out
+
+    def _flush_elbo(self, split):
+        tracker = getattr(self, f"{split}_mol")
+        if tracker is not None:
+            for key, value in tracker.compute().items():
+                self.log(key, value)
+            tracker.reset()
+        self.log(f"{split}/epoch_NLL", getattr(self, f"{split}_nll").compute())
+        self.log(f"{split}/X_kl", getattr(self, f"{split}_X_kl").compute() * self.T)
+        self.log(f"{split}/E_kl", getattr(self, f"{split}_E_kl").compute() * self.T)
+        self.log(f"{split}/X_logp", getattr(self, f"{split}_X_logp").compute())
+        self.log(f"{split}/E_logp", getattr(self, f"{split}_E_logp").compute())
+        for name in ("nll", "X_kl", "E_kl", "X_logp", "E_logp"):
+            getattr(self, f"{split}_{name}").reset()
+
+    def on_validation_epoch_end(self):
+        super().on_validation_epoch_end()
+        if self.phase in ("pretrain_target", "finetune"):
+            return
+        self.last_val_samples = None
+        if getattr(self, "current_epoch", 0) % self.sample_every_val == 0 and getattr(self, "_val_embeddings_buffer", None):
+            logger.info("Performing validation sampling at epoch %s", self.current_epoch)
+            self.last_val_samples = self._sample_buffered("val", self.val_samples_per_embedding)
+        self._flush_elbo("val")
+
+    def on_test_epoch_end(self):
+        super().on_test_epoch_end()
+        if self.phase in ("pretrain_target", "finetune"):
+            return
+        self.last_test_samples = self._sample_buffered("test", self.test_samples_per_embedding) or None
+        self._flush_elbo("test")
 
     # ------------------------------------------------------------------ sampling
     def sample_p_zs_given_zt(self, s, t, X_t, E_t, drug_embeddings, node_mask):
@@ -623,7 +549,7 @@ class FullDTIModel(_Base):
         gd.X_extra, gd.y_extra = self.get_extra_features(X_t, E_t, {"t": t}, node_mask)
         pred = self.denoise_drug_graph(EmbeddingData(drug_embedding=drug_embeddings), BatchData(graph_data=gd))
         mx, me = self._marginals(dev)
-        eX, eE = exp_draws(bs * n, cx, dev), exp_draws(bs * n * n, E_t.shape[-1], dev)
+        eX, eE = self._exp_pair(bs, n, cx, E_t.shape[-1], dev)
         _, _, X_s, E_s = ops.reverse_sample(pred.X, pred.E, X_t.float(), E_t.float(), node_mask, beta_t, a_s, a_t, mx, me, eX, eE)
         return PlaceHolder(X=X_s, E=E_s, y=torch.zeros(bs, 0, device=dev)).type_as(drug_embeddings)
 
@@ -638,8 +564,10 @@ class FullDTIModel(_Base):
         bs = drug_embeddings.size(0)
         n_max = int(n_nodes.max().item())
         node_mask = torch.arange(n_max, device=dev).unsqueeze(0) < n_nodes.unsqueeze(1)
-        zT = sample_discrete_feature_noise(self.limit_dist, node_mask)
+        lim = (self._replayed("expX", dev), self._replayed("expE", dev))
+        zT = sample_discrete_feature_noise(self.limit_dist, node_mask, exp=lim if lim[0] is not None else None)
         X, E = zT.X, zT.E
+        trace = (self.replay or {}).get("trajectory")      # optional list: collapsed class ids after every reverse step
         ones = torch.ones((bs, 1), dtype=self.model_dtype, device=dev)
         steps = list(reversed(range(self.T)))
         self.drug_decoder.prepare_padding_shortcuts(node_mask)     # the same mask for all T steps (and before any capture)
@@ -664,6 +592,9 @@ class FullDTIModel(_Base):
             for s_int in steps:
                 z = self.sample_p_zs_given_zt(s_int * ones / self.T, (s_int + 1) * ones / self.T, X, E, drug_embeddings, node_mask)
                 X, E = z.X, z.E
+                if trace is not None:
+                    c = PlaceHolder(X=X.clone(), E=E.clone()).mask(node_mask, collapse=True)
+                    trace.append((c.X.cpu(), c.E.cpu()))
         final = PlaceHolder(X=X, E=E).mask(node_mask, collapse=True)
         Xc, Ec = final.X.cpu(), final.E.cpu()
         return [(Xc[i, :k], Ec[i, :k, :k]) for i, k in enumerate(n_nodes.cpu().tolist())]

@@ -213,3 +213,37 @@ def compute_Lt_terms(T, mx, me, X, E, X_t, E_t, pred_X_logits, pred_E_logits, no
     kl_x = F.kl_div(torch.log(torch.clamp(pX_, min=1e-8)), tX, reduction="sum") / bs
     kl_e = F.kl_div(torch.log(torch.clamp(pE_, min=1e-8)), tE, reduction="sum") / bs
     return tX, tE, pX_, pE_, T * (kl_x + kl_e)
+
+
+# --------------------------------------------------------------------------- ELBO estimator (validation / test)
+def reconstruction_probs(sched, mx, me, X, E, node_mask, expX, expE, denoise):
+    """t = 0 term of the ELBO (reference mb_vae_dti/training/modules/full.py:680-761): draw G_0 ~ q(G_0 | G) with
+    Q_0 = (1 - beta_0) I + beta_0 1 m^T, one-hot it WITHOUT masking, let `denoise(X0, E0, t0)` return logits, softmax,
+    and set masked nodes / masked pairs / the diagonal to all-ones rows.  Returns (probX0, probE0, X0, E0)."""
+    bs, n = node_mask.shape
+    t0 = torch.zeros(bs, 1)
+    beta0 = sched.beta(t_normalized=t0)
+    probX = X @ Qt(beta0, mx)
+    probE = E @ Qt(beta0, me).unsqueeze(1)
+    Xc, Ec = sample_graph(probX, probE, node_mask, expX, expE)
+    X0, E0 = F.one_hot(Xc, mx.numel()).float(), F.one_hot(Ec, me.numel()).float()
+    lX, lE = denoise(X0, E0, t0)
+    pX, pE = torch.softmax(lX, -1), torch.softmax(lE, -1)
+    pair = node_mask.unsqueeze(1) & node_mask.unsqueeze(2) & ~torch.eye(n, dtype=torch.bool).unsqueeze(0)
+    pX = torch.where(node_mask.unsqueeze(-1), pX, torch.ones_like(pX))
+    pE = torch.where(pair.unsqueeze(-1), pE, torch.ones_like(pE))
+    return pX, pE, X0, E0
+
+
+def val_nll(sched, mx, me, node_hist_prob, X, E, X_t, E_t, pred_X_logits, pred_E_logits, node_mask, noise, probX0, probE0):
+    """Batch NLL estimate and its parts (reference full.py:764-813 with the single-update metric semantics of
+    metrics/graph_metrics.py:13-65): -log p(N) + KL prior + T * KL(posteriors) - E_q log p(G | G_0), where the two
+    batch-level terms are scalars broadcast over the per-graph ones, then averaged."""
+    bs = X.shape[0]
+    N = node_mask.sum(1).long()
+    log_pN = torch.log(node_hist_prob[N] + 1e-6)
+    klp = kl_prior(sched, mx, me, X, E, node_mask)
+    *_, Lt = compute_Lt_terms(sched.T, mx, me, X, E, X_t, E_t, pred_X_logits, pred_E_logits, node_mask, noise)
+    term0 = ((X * torch.clamp(probX0, min=1e-8).log()).sum() + (E * torch.clamp(probE0, min=1e-8).log()).sum()) / bs
+    nlls = -log_pN + klp + Lt - term0
+    return nlls.mean(), {"kl_prior": klp, "Lt": Lt, "log_pN": log_pN, "loss_term_0": term0}

@@ -80,27 +80,33 @@ def eigen_features(E_t, node_mask, lcc_noise, k_vals=5, k_vecs=2):
 BOND_ORDERS = (0.0, 1.0, 2.0, 3.0, 1.5)
 
 
-def molecular_features(X_t, E_t, valencies, atom_weights, max_weight):
+def molecular_features(X_t, E_t, valencies, atom_weights, max_weight, truncate_weight=False):
     """charge [bs,n], valency [bs,n], weight [bs,1].  NB the reference takes the *argmax* of
     one_hot*order, i.e. the class index where order>0 (aromatic counts 4, not 1.5) and 0 for
-    no-bond -- an integer 'valency'."""
+    no-bond -- an integer 'valency'.
+    truncate_weight: FullDTIModel.apply_noise returns int64 one-hots (modules/full.py:500-507), and WeightFeature
+    casts the summed atomic weight with `.type_as(X)` before dividing (diffusion/augmentation.py:311-314): on the
+    train / validation path the weight is therefore truncated to an integer; the sampling and t = 0 paths pass
+    float one-hots and keep the fraction."""
     orders = torch.tensor(BOND_ORDERS).reshape(1, 1, 1, -1)
     cur = (E_t * orders).argmax(-1).sum(-1)
     normal = (X_t * torch.tensor(valencies).reshape(1, 1, -1)).argmax(-1)
     charge = (normal - cur).float()
     valency = cur.float()
-    weight = torch.tensor(atom_weights)[X_t.argmax(-1)].sum(-1, keepdim=True).float() / max_weight
-    return charge, valency, weight
+    weight = torch.tensor(atom_weights)[X_t.argmax(-1)].sum(-1, keepdim=True).float()
+    if truncate_weight:
+        weight = torch.trunc(weight)
+    return charge, valency, weight / max_weight
 
 
-def extra_features(X_t, E_t, t, node_mask, lcc_noise, max_n_nodes, valencies, atom_weights, max_weight):
+def extra_features(X_t, E_t, t, node_mask, lcc_noise, max_n_nodes, valencies, atom_weights, max_weight, truncate_weight=False):
     """X_extra [bs,n,8], y_extra [bs,13] as fed to the denoiser."""
     A = E_t[..., 1:].sum(-1).float()
     xc, yc = cycle_features(A)
     xc = torch.clamp(xc * node_mask.unsqueeze(-1) / 10, max=1.0)
     yc = torch.clamp(yc / 10, max=1.0)
     ncc, vals, not_lcc, vecs = eigen_features(E_t, node_mask, lcc_noise)
-    charge, valency, weight = molecular_features(X_t, E_t, valencies, atom_weights, max_weight)
+    charge, valency, weight = molecular_features(X_t, E_t, valencies, atom_weights, max_weight, truncate_weight)
     n_frac = node_mask.sum(1, keepdim=True) / max_n_nodes
     X_extra = torch.cat((xc, not_lcc, vecs, charge.unsqueeze(-1), valency.unsqueeze(-1)), -1)
     y_extra = torch.cat((n_frac, yc, ncc.float(), vals, weight, t), 1)

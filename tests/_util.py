@@ -24,11 +24,14 @@ def load_golden(name):
 
 
 def assert_close(a, b, rtol=1e-5, atol=None, what=""):
-    """max |a-b| <= rtol * max(1, max|b|)  (relative to the tensor's scale, as the parity bar is stated)."""
+    """max |a - b| <= rtol * max |b|: the error relative to the reference tensor's own scale (1e-5 unless a test states
+    and justifies another figure).  No floor on the scale: a gradient tensor of magnitude 1e-3 must be right to 1e-8.
+    atol (absolute) replaces the relative bound where the reference is exactly zero or a difference of O(1) terms."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
-    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    assert bool(torch.isfinite(a).all()), f"{what}: non-finite values"
+    scale = float(b.abs().max()) if b.numel() else 0.0
     err = float((a - b).abs().max()) if b.numel() else 0.0
     tol = rtol * scale if atol is None else atol
-    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e}, rel {err / max(scale, 1e-300):.2e})"

@@ -1,0 +1,322 @@
+"""GPU parity of the model-level paths against fixtures captured from the reference: stand-alone encoders /
+aggregators / fusion / heads (values and gradients), the four non-diffusion model variants, the validation ELBO step,
+a five-step sampling trajectory, the epoch-end hooks.  Everything runs through the HIP library (C ABI).
+
+Tolerance: 1e-5 of the reference tensor's largest magnitude unless stated next to the check.
+"""
+import pytest
+import torch
+import torch.nn as nn
+
+from tests._util import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+# Gradients that are exactly zero in exact arithmetic (softmax shift invariance): both sides hold rounding noise.
+def _is_null_grad(key):
+    return key.endswith("to_attn_logits.bias")
+
+
+# ------------------------------------------------------------------------------------------------ blocks / heads
+def _block_cases(g):
+    from mbvae_amd import blocks, heads
+    relu = nn.ReLU()
+    feats = [g["f0"], g["f1"], g["f2"]]
+    return {
+        "resenc": (blocks.ResidualEncoder(40, 16, 24, n_layers=2, factor=4, dropout=0.1), lambda m, l: [m(l[0])], [g["xin"]]),
+        "trfenc": (blocks.TransformerEncoder(40, 16, 24, n_layers=2, factor=4, dropout=0.1), lambda m, l: [m(l[0])], [g["xin"]]),
+        "concat": (blocks.ConcatAggregator(16, 24, 3), lambda m, l: [m(l)], feats),
+        "attagg": (blocks.AttentiveAggregator(16, 24, 3), lambda m, l: [m(l)[0]], feats),
+        "fusion": (blocks.CrossAttentionFusion(24, 16, n_layers=2, factor=4, dropout=0.1), lambda m, l: [m(l[0], l[1])[0]], [g["a"], g["b"]]),
+        "dtihead": (heads.DTIHead(16, 8, 0.1, True, relu), lambda m, l: list(m(l[0]).values()), [g["h16"]]),
+        "infonce": (heads.InfoNCEHead(24, 8, 0.1, True, relu), lambda m, l: [m(l[0], g["fp"].cuda(), 0.1)], [g["a"]]),
+    }
+
+
+@pytest.mark.parametrize("name", ["resenc", "trfenc", "concat", "attagg", "fusion", "dtihead", "infonce"])
+def test_blocks_and_heads_golden(name):
+    """ResidualEncoder, TransformerEncoder, ConcatAggregator, AttentiveAggregator, CrossAttentionFusion, DTIHead and
+    InfoNCEHead on their own: outputs, parameter gradients and input gradients."""
+    g = load_golden("encoders")
+    mod, fn, ins = _block_cases(g)[name]
+    missing, unexpected = mod.load_state_dict(g["sd_" + name], strict=True)
+    mod = mod.cuda().eval()
+    leaves = [t.clone().cuda().requires_grad_(True) for t in ins]
+    outs = fn(mod, leaves)
+    want = {"resenc": ["resenc_out"], "trfenc": ["trfenc_out"], "concat": ["concat_out"], "attagg": ["attagg_out"],
+            "fusion": ["fusion_out"], "dtihead": ["dtihead_Y", "dtihead_Y_pKd", "dtihead_Y_pKi", "dtihead_Y_KIBA"],
+            "infonce": ["infonce_loss"]}[name]
+    for o, k in zip(outs, want):
+        assert_close(o, g[k], what=f"{name} {k}")
+    if name in ("attagg", "fusion"):
+        w = mod([l.detach() for l in leaves])[1] if name == "attagg" else mod(leaves[0].detach(), leaves[1].detach())[1]
+        assert_close(w, g[name + "_w"], what=name + " attention weights")
+    sum((o * g[f"{name}_cot{i}"].cuda()).sum() for i, o in enumerate(outs)).backward()
+    params = dict(mod.named_parameters())
+    for k, v in g["pg_" + name].items():
+        # reductions over <= 64 terms per element: 2e-5 covers the different summation order of the MFMA tiles
+        assert_close(params[k].grad, v, rtol=2e-5, atol=1e-6 if _is_null_grad(k) else None, what=f"{name} grad {k}")
+    for i, t in enumerate(leaves):
+        assert_close(t.grad, g[f"{name}_din{i}"], rtol=2e-5, what=f"{name} input grad {i}")
+
+
+# ------------------------------------------------------------------------------------------------ model variants
+COMMON = dict(learning_rate=1e-3, weight_decay=1e-4, scheduler="const", embedding_dim=32, hidden_dim=16, factor=4, n_layers=2,
+              activation="relu", dropout=0.1, bias=True)
+DTI_W = [1.0, 0.903964, 0.282992, 0.755172]
+VIEWS_D = {"FP-Morgan": 64, "EMB-BiomedGraph": 24, "EMB-BiomedText": 20}
+VIEWS_T = {"FP-ESP": 48, "EMB-ESM": 40}
+
+
+def _variant(name):
+    from mbvae_amd import variants as V
+    if name == "baseline":
+        return V.BaselineDTIModel(phase="finetune", finetune_score="Y_pKd", drug_features={"FP-Morgan": 64}, target_features={"FP-ESP": 48},
+                                  encoder_type="transformer", **COMMON)
+    if name == "baseline_resnet":
+        return V.BaselineDTIModel(phase="finetune", finetune_score="Y_KIBA", drug_features={"FP-Morgan": 64}, target_features={"FP-ESP": 48},
+                                  encoder_type="resnet", **COMMON)
+    if name == "multi_modal":
+        return V.MultiModalDTIModel(phase="finetune", finetune_score="Y_pKd", drug_features=VIEWS_D, target_features=VIEWS_T,
+                                    encoder_type="resnet", aggregator_type="concat", **COMMON)
+    if name == "multi_output":
+        return V.MultiOutputDTIModel(phase="train", finetune_score=None, drug_features={"FP-Morgan": 64}, target_features={"FP-ESP": 48},
+                                     encoder_type="transformer", dti_weights=DTI_W, **COMMON)
+    return V.MultiHybridDTIModel(phase="train", finetune_score=None, weights=[1.0, 0.0, 0.5, 0.0], dti_weights=DTI_W, contrastive_temp=0.1,
+                                 drug_features=VIEWS_D, target_features=VIEWS_T, encoder_type="resnet", aggregator_type="concat", **COMMON)
+
+
+@pytest.mark.parametrize("name", ["baseline", "baseline_resnet", "multi_modal", "multi_output", "multi_hybrid"])
+def test_model_variants_common_step_golden(name):
+    """_common_step of the single-branch MLP model (two encoders -> dot product -> masked MSE) and of the multi-modal /
+    multi-output / multi-hybrid variants: embeddings, scores, loss and EVERY parameter gradient against the reference."""
+    g = load_golden("variants")
+    model = _variant(name)
+    model.load_state_dict(g[name + "_sd"], strict=True)                 # reference checkpoint keys, no remapping
+    model = model.cuda().eval()
+    y = {k: (v.bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
+    batch = {"id": torch.arange(6), "y": y, "drug": {"features": _cuda(g["feat_d"]), "representations": {"smiles": ["C"] * 6}},
+             "target": {"features": _cuda(g["feat_t"])}}
+    bd, emb, pred, loss = model._common_step(batch)
+    assert_close(emb.drug_embedding, g[name + "_drug_embedding"], what="drug embedding")
+    assert_close(emb.target_embedding, g[name + "_target_embedding"], what="target embedding")
+    if name + "_fused" in g:
+        assert_close(emb.fused_embedding, g[name + "_fused"], what="fused embedding")
+    if isinstance(pred.dti_scores, dict):
+        for k, v in pred.dti_scores.items():
+            assert_close(v, g[f"{name}_score_{k}"], what="score " + k)
+    else:
+        assert_close(pred.dti_scores, g[name + "_score"], what="scores")
+    total = loss.compute_loss(model.weights) if hasattr(model, "weights") else loss.accuracy
+    assert_close(total, g[name + "_loss"], what="loss")
+    if name == "multi_hybrid":
+        assert_close(loss.contrastive, g[name + "_contrastive"], what="contrastive")
+    total.backward()
+    params = dict(model.named_parameters())
+    assert set(g[name + "_grad"]) == {k for k, p in params.items() if p.grad is not None}
+    for k, v in g[name + "_grad"].items():
+        # whole-network gradients: chains of <= 12 products with reductions of <= 64 terms; 3e-5 of the tensor's scale
+        assert_close(params[k].grad, v, rtol=3e-5, what="grad " + k)
+    # the Lightning-style steps return the same loss and log it
+    model.zero_grad()
+    batch["y"] = {k: (v.bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
+    out = model.training_step(batch, 0)
+    assert_close(out, g[name + "_loss"], what="training_step")
+
+
+def test_baseline_no_valid_pairs_gives_zero_loss():
+    g = load_golden("variants")
+    model = _variant("baseline").cuda().eval()
+    y = {k: (torch.zeros_like(v).bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
+    batch = {"y": y, "drug": {"features": _cuda(g["feat_d"])}, "target": {"features": _cuda(g["feat_t"])}}
+    *_, loss = model._common_step(batch)
+    assert float(loss.accuracy) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ full model: ELBO step
+def _tiny_full(g, T=500, phase="pretrain_drug"):
+    from mbvae_amd.full import FullDTIModel
+    cx, emb, hid = 8, 32, 16
+    infos = {"general": {"atom_types": ["C", "O", "P", "N", "S", "Cl", "F", "H"], "max_n_nodes": 64,
+                         "atom_valencies": [4, 2, 3, 3, 2, 1, 1, 1],
+                         "atom_weights": [12.011, 15.999, 30.974, 14.007, 32.06, 35.45, 18.998, 1.008], "max_weight": 1000},
+             "dataset": {"node_count_distribution": {"3": 1, "5": 2, "7": 3, "9": 2}, "node_marginals": g["mx"].tolist(),
+                         "edge_marginals": g["me"].tolist()}}
+    gt = dict(n_layers=2, input_dims={"X": cx + 8, "E": 5, "y": emb + 13}, output_dims={"X": cx, "E": 5, "y": emb},
+              hidden_mlp_dims={"X": 24, "E": 16, "y": 40},
+              hidden_dims={"dx": 32, "de": 16, "dy": 32, "n_head": 4, "dim_ffX": 24, "dim_ffE": 16, "dim_ffy": 40})
+    model = FullDTIModel(
+        phase=phase, finetune_score=None, learning_rate=5e-4, weight_decay=1e-4, scheduler="const", weights=[1.0, 0.001, 0.5, 3.0],
+        dti_weights=None, diff_weights=[1, 5], contrastive_temp=0.1, drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 24},
+        target_features={}, embedding_dim=emb, hidden_dim=hid, factor=4, n_layers=2, activation="relu", dropout=0.1, bias=True,
+        encoder_type="transformer", aggregator_type="attentive", diffusion_steps=T, sample_every_val=5,
+        val_samples_per_embedding=2, test_samples_per_embedding=2, graph_transformer_kwargs=gt, dataset_infos=infos)
+    sd = {k: v for k, v in g["sd"].items() if not (k == "noise_schedule.betas" and v.numel() != T + 1)}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if k != "noise_schedule.betas"], missing
+    return model.cuda().eval()
+
+
+def _check_own_eigvec(model, ref_vec, mask):
+    """The HIP eigensolver's two eigenvector features agree with the reference's up to the sign of each column
+    (non-degenerate spectra) -- the replay then continues on the reference's gauge."""
+    own = model.graph_structure_features.last_eigvec.cpu()
+    for b in range(own.shape[0]):
+        for c in range(2):
+            a, r = own[b, :, c], ref_vec[b, :, c]
+            if float(r.abs().max()) < 1e-6:
+                continue
+            same, flip = float((a - r).abs().max()), float((a + r).abs().max())
+            if min(same, flip) > 2e-4:       # a degenerate eigenvalue pair: any rotation of the pair is valid
+                continue
+            assert min(same, flip) <= 2e-4
+
+
+def test_validation_step_elbo_golden():
+    """validation_step on the reference's own draws: noised graph bit-exact, logits, the t = 0 reconstruction
+    probabilities, every ELBO term, the NLL, the logged epoch metrics after on_validation_epoch_end."""
+    from mbvae_amd.containers import GraphData
+    g = load_golden("val_step")
+    model = _tiny_full(g)
+    mask = g["mask"].bool().cuda()
+    model.replay = {"t_int": g["t_int"], "eps": g["eps"], "expX": [g["expX"], g["expX0"]], "expE": [g["expE"], g["expE0"]],
+                    "lcc_noise": [g["lcc_noise"], g["lcc_noise0"]], "eigvec": [g["X_extra"][..., 4:6], g["X_extra0"][..., 4:6]]}
+    batch = {"features": _cuda(g["feat"]), "representations": {"smiles": ["C"] * 4},
+             "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}
+    seen = {}
+    orig = model.reconstruction_logp
+
+    def logp(*a, **k):
+        out = orig(*a, **k)
+        seen["X"], seen["E"] = out
+        return out
+
+    model.reconstruction_logp = logp
+    with torch.no_grad():
+        bd, emb, pred, loss = model._common_step(batch, "val")
+    gd = bd.graph_data
+    assert torch.equal(gd.X_t.cpu(), g["X_t"]) and torch.equal(gd.E_t.cpu(), g["E_t"])
+    assert_close(gd.X_extra, g["X_extra"], what="X_extra (reference gauge)"); assert_close(gd.y_extra, g["y_extra"], what="y_extra")
+    out = pred.graph_reconstruction
+    # two layers deep, every output a chain of ~20 products over reductions of <= 81 pairs: 2e-5 of the logit scale
+    assert_close(out.X, g["pred_X"], rtol=2e-5, what="logits X"); assert_close(out.E, g["pred_E"], rtol=2e-5, what="logits E")
+    assert_close(seen["X"], g["probX0"], rtol=2e-5, what="probX0"); assert_close(seen["E"], g["probE0"], rtol=2e-5, what="probE0")
+    parts = loss.components
+    assert_close(parts["kl prior"], g["kl_prior"], what="KL prior"); assert_close(parts["log_pn"], g["log_pn"], what="log p(N)")
+    # T * KL and the t = 0 term sum ~400 log-probabilities each: 2e-5 of their value
+    assert_close(parts["Estimator loss terms"], g["Lt"], rtol=2e-5, what="T * KL"); assert_close(parts["loss_term_0"], g["loss_term_0"], rtol=2e-5, what="t = 0 term")
+    assert_close(loss.reconstruction, g["nll"], rtol=2e-5, what="NLL")
+    assert_close(loss.complexity, g["loss_complexity"], what="KL"); assert_close(loss.contrastive, g["loss_contrastive"], what="contrastive")
+    assert_close(loss.compute_loss(model.weights), g["loss_total"], rtol=2e-5, what="total")
+    assert not model.replay["expX"] and not model.replay["lcc_noise"], "the step must have consumed both sets of draws"
+    # epoch end: the five running ELBO metrics are logged and reset (sampling skipped: no buffered embeddings here)
+    model.on_validation_epoch_end()
+    for key, ref in (("val/epoch_NLL", "epoch_NLL"), ("val/X_kl", "epoch_X_kl"), ("val/E_kl", "epoch_E_kl"), ("val/X_logp", "epoch_X_logp"),
+                     ("val/E_logp", "epoch_E_logp")):
+        assert_close(torch.as_tensor(model.logged[key]), g[ref], rtol=2e-5, what=key)
+    assert model.val_nll.count == 0 and model.val_X_kl.count == 0
+
+
+def test_sampling_trajectory_golden():
+    """sample_batch (T = 5) on the reference's draws: the limit-distribution start and the class ids after every one of
+    the five reverse steps are identical to the reference's, bit for bit."""
+    g = load_golden("trajectory")
+    T = int(g["T"])
+    model = _tiny_full(g, T=T)
+    mask = g["mask"].bool()
+    from mbvae_amd.containers import PlaceHolder
+    from mbvae_amd.diffusion import sample_discrete_feature_noise
+    z = sample_discrete_feature_noise(model.limit_dist, mask.cuda(), exp=(g["expX_0"], g["expE_0"]))
+    assert torch.equal(z.X.cpu(), g["z_T_X"]) and torch.equal(z.E.cpu(), g["z_T_E"]), "limit-distribution sample"
+    trace = []
+    model.replay = {"expX": [g[f"expX_{k}"] for k in range(T + 1)], "expE": [g[f"expE_{k}"] for k in range(T + 1)],
+                    "lcc_noise": [g[f"lcc_{k}"] for k in range(T)], "eigvec": [g[f"eigvec_{k}"] for k in range(T)], "trajectory": trace}
+    groups = model.sample_batch(g["emb"].cuda(), num_nodes=g["n_nodes"], num_samples_per_embedding=1, return_graphs=True)
+    assert len(trace) == T
+    for k, (cX, cE) in enumerate(trace):
+        assert torch.equal(cX, g[f"traj_X_{k}"]) and torch.equal(cE, g[f"traj_E_{k}"]), f"reverse step {k}"
+    for (atoms, bonds), n, b in zip((grp[0] for grp in groups), g["n_nodes"].tolist(), range(5)):
+        assert torch.equal(atoms, g[f"traj_X_{T - 1}"][b, :n]) and torch.equal(bonds, g[f"traj_E_{T - 1}"][b, :n, :n])
+
+
+def test_limit_noise_golden():
+    g = load_golden("noise")
+    from mbvae_amd.containers import PlaceHolder
+    from mbvae_amd.diffusion import sample_discrete_feature_noise
+    lim = PlaceHolder(X=g["mx"], E=g["me"])
+    z = sample_discrete_feature_noise(lim, g["mask"].bool().cuda(), exp=(g["lim_expX"], g["lim_expE"]))
+    assert torch.equal(z.X.cpu(), g["lim_X"]) and torch.equal(z.E.cpu(), g["lim_E"])
+
+
+def test_own_eigenvector_features_match_reference_up_to_sign():
+    g = load_golden("val_step")
+    model = _tiny_full(g)
+    mask = g["mask"].bool().cuda()
+    model.get_extra_features(g["X_t"].cuda(), g["E_t"].cuda(), {"t": torch.zeros(4, 1).cuda()}, mask)
+    _check_own_eigvec(model, g["X_extra"][..., 4:6], mask)
+
+
+# ------------------------------------------------------------------------------------------------ epoch-end hooks
+class _MolTracker:
+    def __init__(self):
+        self.updates, self.resets = [], 0
+
+    def update(self, generated_mols, target_smiles):
+        self.updates.append((generated_mols, list(target_smiles)))
+
+    def compute(self):
+        return {"val/validity": float(len(self.updates))}
+
+    def reset(self):
+        self.resets += 1
+
+
+def test_epoch_end_hooks_sample_log_and_reset():
+    """on_validation_epoch_end samples from the buffered embeddings every sample_every_val epochs, feeds the molecule
+    tracker with (groups, SMILES slice), logs and resets the ELBO trackers; on_train_epoch_end logs the per-class CE
+    trackers; on_test_epoch_end likewise with the test buffers."""
+    from mbvae_amd.containers import GraphData
+    g = load_golden("val_step")
+    model = _tiny_full(g, T=3)
+    mask = g["mask"].bool().cuda()
+    batch = {"features": _cuda(g["feat"]), "representations": {"smiles": ["C", "CC", "CCC", "CCCC"]},
+             "G": GraphData(X=g["X"].cuda(), E=g["E"].cuda(), node_mask=mask)}
+    model.val_mol = _MolTracker()
+    with torch.no_grad():
+        model.validation_step(batch, 0)
+        model.validation_step(batch, 1)
+    assert len(model._val_embeddings_buffer) == 2 and model.val_nll.count == 8
+    model.current_epoch = 1                    # 1 % 5 != 0: no sampling, buffers kept, metrics still flushed
+    model.on_validation_epoch_end()
+    assert model.last_val_samples is None and len(model._val_embeddings_buffer) == 2 and model.val_nll.count == 0
+    assert torch.isfinite(torch.as_tensor(model.logged["val/epoch_NLL"]))
+    model.current_epoch = 5
+    with torch.no_grad():
+        model.validation_step(batch, 0)
+    model.on_validation_epoch_end()
+    assert len(model.last_val_samples) == 3 and not hasattr(model, "_val_embeddings_buffer")
+    assert len(model.val_mol.updates) == 3 and model.val_mol.resets == 2
+    mols, smiles = model.val_mol.updates[1]
+    assert smiles == ["C", "CC", "CCC", "CCCC"] and len(mols) == 4 and all(len(grp) == 2 for grp in mols)
+    assert model.logged["val/validity"] == 3.0
+    # test epoch
+    with torch.no_grad():
+        model.test_step(batch, 0)
+    model.on_test_epoch_end()
+    assert len(model.last_test_samples) == 1 and "test/epoch_NLL" in model.logged and model.test_nll.count == 0
+    # train epoch: per-class CE trackers
+    model.train()
+    model.training_step(batch, 0)
+    model.on_train_epoch_end()
+    assert "train/atom_CCE" in model.logged and "train/bond_AromaticCE" in model.logged and model.train_mol.atom_sum is None

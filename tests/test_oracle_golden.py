@@ -135,3 +135,137 @@ def test_reverse_step_with_network():
     Xc, Ec = O_dif.sample_graph(pX, pE, mask, g["expX"], g["expE"])
     Xs, Es = O_dif.one_hot_masked(Xc, Ec, mask, 8, 5)
     assert torch.equal(Xs, g["X_s"]) and torch.equal(Es, g["E_s"])
+
+
+def test_encoder_fusion_head_gradients():
+    """Parameter and input gradients of the encoders / aggregators / fusion / heads (autograd through the oracle)."""
+    import torch.nn.functional as F  # noqa: F401
+    g = load_golden("encoders")
+    feats = [g["f0"], g["f1"], g["f2"]]
+    cases = {
+        "resenc": (lambda p, l: [O_heads.residual_encoder(p, l[0])], [g["xin"]]),
+        "trfenc": (lambda p, l: [O_heads.transformer_encoder(p, l[0])], [g["xin"]]),
+        "concat": (lambda p, l: [O_heads.concat_aggregator(p, l)], feats),
+        "attagg": (lambda p, l: [O_heads.attentive_aggregator(p, l)[0]], feats),
+        "fusion": (lambda p, l: [O_heads.cross_attention_fusion(p, l[0], l[1])[0]], [g["a"], g["b"]]),
+        "dtihead": (lambda p, l: list(O_heads.dti_head(p, l[0]).values()), [g["h16"]]),
+        "infonce": (lambda p, l: [O_heads.info_nce(p, l[0], g["fp"], 0.1)], [g["a"]]),
+    }
+    for nm, (fn, ins) in cases.items():
+        p = {k: v.clone().requires_grad_(True) for k, v in g["sd_" + nm].items()}
+        leaves = [t.clone().requires_grad_(True) for t in ins]
+        outs = fn(p, leaves)
+        sum((o * g[f"{nm}_cot{i}"]).sum() for i, o in enumerate(outs)).backward()
+        for k, v in g["pg_" + nm].items():
+            # softmax is shift invariant: the gradient of the attention-logit bias is exactly zero in exact arithmetic,
+            # and what both sides hold is rounding noise (1e-8) -- compared absolutely
+            assert_close(p[k].grad, v, rtol=2e-5, atol=1e-6 if k.endswith("to_attn_logits.bias") else None, what=f"{nm} grad {k}")
+        for i, t in enumerate(leaves):
+            assert_close(t.grad, g[f"{nm}_din{i}"], rtol=2e-5, what=f"{nm} input grad {i}")
+
+
+def _oracle_denoise(g, sd_prefix, emb, mask, n_layers=2, n_head=4, cx=8):
+    dec = {k[len(sd_prefix):]: v for k, v in g["sd"].items() if k.startswith(sd_prefix)}
+
+    def run(Xn, En, X_extra, y_extra):
+        oX, oE, _ = O_den.graph_transformer(dec, torch.cat([Xn, X_extra], 2), En, torch.cat([emb, y_extra], 1), mask, n_layers, n_head,
+                                            {"X": cx, "E": 5, "y": 32})
+        return oX, oE
+    return run
+
+
+def test_validation_elbo_step():
+    """The whole NLL estimator of a validation step (noise -> denoiser -> KL prior + T*KL + t=0 reconstruction) on the
+    reference's own random draws."""
+    g = load_golden("val_step")
+    mask = g["mask"].bool()
+    sch = O_dif.Schedule(500)
+    mx, me = g["mx"], g["me"]
+    X_t, E_t, npar, _, _ = O_dif.apply_noise(sch, mx, me, g["X"], g["E"], mask, g["t_int"], g["expX"], g["expE"])
+    assert torch.equal(X_t, g["X_t"]) and torch.equal(E_t, g["E_t"])
+    enc = {k[len("drug_encoders."):]: v for k, v in g["sd"].items() if k.startswith("drug_encoders.")}
+    views = [O_heads.transformer_encoder({k[len(nm) + 1:]: v for k, v in enc.items() if k.startswith(nm + ".")}, g["feat"][nm])
+             for nm in ("FP-Morgan", "EMB-BiomedGraph")]
+    agg, _ = O_heads.attentive_aggregator({k[len("drug_aggregator."):]: v for k, v in g["sd"].items() if k.startswith("drug_aggregator.")}, views)
+    z, mu, lv = O_heads.kl_head({k[len("drug_kl_head."):]: v for k, v in g["sd"].items() if k.startswith("drug_kl_head.")}, agg, g["eps"])
+    assert_close(O_heads.kl_divergence(mu, lv), g["loss_complexity"], what="KL")
+    run = _oracle_denoise(g, "drug_decoder.", z, mask)
+    with torch.no_grad():
+        lX, lE = run(X_t, E_t, g["X_extra"], g["y_extra"])
+        assert_close(lX, g["pred_X"], rtol=2e-5, what="logits X"); assert_close(lE, g["pred_E"], rtol=2e-5, what="logits E")
+        pX0, pE0, _, _ = O_dif.reconstruction_probs(sch, mx, me, g["X"], g["E"], mask, g["expX0"], g["expE0"],
+                                                    lambda a, b, t0: run(a, b, g["X_extra0"], g["y_extra0"]))
+        assert_close(pX0, g["probX0"], rtol=2e-5, what="probX0"); assert_close(pE0, g["probE0"], rtol=2e-5, what="probE0")
+        hist = torch.zeros(10); hist[[3, 5, 7, 9]] = torch.tensor([1., 2., 3., 2.]); hist = hist / hist.sum()
+        nll, parts = O_dif.val_nll(sch, mx, me, hist, g["X"], g["E"], X_t, E_t, lX, lE, mask, npar, pX0, pE0)
+    assert_close(nll, g["nll"], rtol=2e-5, what="NLL"); assert_close(parts["Lt"], g["Lt"], rtol=2e-5, what="Lt")
+    assert_close(parts["loss_term_0"], g["loss_term_0"], rtol=2e-5, what="t=0 term")
+    assert_close(parts["kl_prior"].mean(), g["kl_prior"], what="KL prior"); assert_close(parts["log_pN"].mean(), g["log_pn"], what="log pN")
+    assert_close(nll, g["epoch_NLL"], rtol=2e-5, what="epoch NLL (single batch)")
+
+
+def test_sampling_trajectory_five_steps():
+    """sample_batch's reverse loop (T = 5): every step's class ids, bit for bit, on the reference's draws."""
+    g = load_golden("trajectory")
+    mask = g["mask"].bool()
+    T = int(g["T"])
+    sch = O_dif.Schedule(T)
+    mx, me = g["mx"], g["me"]
+    X, E = O_dif.sample_limit(mx, me, mask, g["expX_0"], g["expE_0"])
+    assert torch.equal(X, g["z_T_X"]) and torch.equal(E, g["z_T_E"])
+    run = _oracle_denoise(g, "drug_decoder.", g["emb"], mask)
+    bs = mask.shape[0]
+    with torch.no_grad():
+        for k, s_int in enumerate(reversed(range(T))):
+            s = torch.full((bs, 1), float(s_int)) / T; t = torch.full((bs, 1), float(s_int + 1)) / T
+            Xe, ye = O_feat.extra_features(X, E, t, mask, g[f"lcc_{k}"], 64, [4, 2, 3, 3, 2, 1, 1, 1],
+                                           [12.011, 15.999, 30.974, 14.007, 32.06, 35.45, 18.998, 1.008], 1000)
+            Xe = torch.cat((Xe[..., :4], g[f"eigvec_{k}"], Xe[..., 6:]), -1)
+            oX, oE = run(X, E, Xe, ye)
+            pX, pE = O_dif.reverse_step_probs(oX, oE, X, E, sch.beta(t_normalized=t), sch.alpha_bar(t_normalized=s),
+                                              sch.alpha_bar(t_normalized=t), mx, me)
+            Xc, Ec = O_dif.sample_graph(pX, pE, mask, g[f"expX_{k + 1}"], g[f"expE_{k + 1}"])
+            X, E = O_dif.one_hot_masked(Xc, Ec, mask, 8, 5)
+            cX = torch.where(mask, Xc, torch.full_like(Xc, -1))
+            cE = torch.where(mask.unsqueeze(1) & mask.unsqueeze(2), Ec, torch.full_like(Ec, -1))
+            assert torch.equal(cX, g[f"traj_X_{k}"]) and torch.equal(cE, g[f"traj_E_{k}"]), f"step {k}"
+
+
+def test_model_variants_losses():
+    """Baseline / multi-modal / multi-output / multi-hybrid _common_step: embeddings, scores and losses composed from the
+    oracle's encoders, aggregators, fusion and heads."""
+    g = load_golden("variants")
+    fd, ft, y = g["feat_d"], g["feat_t"], g["y"]
+    w = [1.0, 0.903964, 0.282992, 0.755172]
+
+    def sub(sd, prefix):
+        return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+    for name, enc_fn, multi in (("baseline", O_heads.transformer_encoder, False), ("baseline_resnet", O_heads.residual_encoder, False),
+                                ("multi_modal", O_heads.residual_encoder, True), ("multi_output", O_heads.transformer_encoder, False),
+                                ("multi_hybrid", O_heads.residual_encoder, True)):
+        sd = g[name + "_sd"]
+        if multi:
+            od = O_heads.concat_aggregator(sub(sd, "drug_aggregator."), [enc_fn(sub(sd, f"drug_encoders.{k}."), fd[k])
+                                                                         for k in ("FP-Morgan", "EMB-BiomedGraph", "EMB-BiomedText")])
+            ot = O_heads.concat_aggregator(sub(sd, "target_aggregator."), [enc_fn(sub(sd, f"target_encoders.{k}."), ft[k])
+                                                                           for k in ("FP-ESP", "EMB-ESM")])
+        else:
+            od, ot = enc_fn(sub(sd, "drug_encoder."), fd["FP-Morgan"]), enc_fn(sub(sd, "target_encoder."), ft["FP-ESP"])
+        assert_close(od, g[name + "_drug_embedding"], what=name + " drug"); assert_close(ot, g[name + "_target_embedding"], what=name + " target")
+        if name in ("baseline", "baseline_resnet", "multi_modal"):
+            key = "Y_KIBA" if name == "baseline_resnet" else "Y_pKd"
+            m = y[key + "_mask"].bool()
+            assert_close((od * ot).sum(-1)[m], g[name + "_score"], what=name + " scores")
+            assert_close(torch.nn.functional.mse_loss((od * ot).sum(-1)[m], y[key][m]), g[name + "_loss"], what=name + " loss")
+        else:
+            fused, _ = O_heads.cross_attention_fusion(sub(sd, "fusion."), od, ot)
+            assert_close(fused, g[name + "_fused"], what=name + " fused")
+            acc, _ = O_heads.dti_accuracy_loss(O_heads.dti_head(sub(sd, "dti_head."), fused), {k: y[k] for k in ("Y", "Y_pKd", "Y_pKi", "Y_KIBA")},
+                                               {k: y[k + "_mask"].bool() for k in ("Y_pKd", "Y_pKi", "Y_KIBA")}, w)
+            if name == "multi_hybrid":
+                con = (O_heads.info_nce(sub(sd, "drug_contrastive_head."), od, fd["FP-Morgan"], 0.1)
+                       + O_heads.info_nce(sub(sd, "target_contrastive_head."), ot, ft["FP-ESP"], 0.1))
+                assert_close(con, g[name + "_contrastive"], what="contrastive")
+                acc = acc + 0.5 * con
+            assert_close(acc, g[name + "_loss"], what=name + " loss")

@@ -378,6 +378,38 @@ def gen_heads():
         for k in d:
             enc["dtihead_" + k] = d[k]; close(od[k], d[k], what="dti " + k)
         enc["infonce_loss"] = mods["infonce"](a, fp, 0.1); close(O_heads.info_nce(mods["infonce"].state_dict(), a, fp, 0.1), enc["infonce_loss"], what="infonce")
+    # gradients (values above were taken without autograd): scalar = sum(output * cotangent), cotangents stored
+    def grads_of(mod, out_fn, ins, tag):
+        mod.zero_grad()
+        leaves = [t.clone().requires_grad_(True) for t in ins]
+        out = out_fn(leaves)
+        outs = out if isinstance(out, (tuple, list)) else [out]
+        cots = [torch.randn(o.shape, generator=g) for o in outs]
+        sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+        for i, c in enumerate(cots):
+            enc[f"{tag}_cot{i}"] = c
+        for i, t in enumerate(leaves):
+            enc[f"{tag}_din{i}"] = t.grad.clone()
+        return {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None}
+
+    pg = {}
+    pg["resenc"] = grads_of(mods["resenc"], lambda l: mods["resenc"](l[0]), [xin], "resenc")
+    pg["trfenc"] = grads_of(mods["trfenc"], lambda l: mods["trfenc"](l[0]), [xin], "trfenc")
+    pg["concat"] = grads_of(mods["concat"], lambda l: mods["concat"](l), feats, "concat")
+    pg["attagg"] = grads_of(mods["attagg"], lambda l: mods["attagg"](l)[0], feats, "attagg")
+    pg["fusion"] = grads_of(mods["fusion"], lambda l: mods["fusion"](l[0], l[1])[0], [a, b], "fusion")
+    pg["dtihead"] = grads_of(mods["dtihead"], lambda l: list(mods["dtihead"](l[0]).values()), [h16], "dtihead")
+    pg["infonce"] = grads_of(mods["infonce"], lambda l: mods["infonce"](l[0], fp, 0.1), [a], "infonce")
+    # the oracle's autograd must give the same parameter gradients
+    for nm, fn, ins in (("resenc", lambda p_, l: O_heads.residual_encoder(p_, l[0]), [xin]),
+                        ("concat", lambda p_, l: O_heads.concat_aggregator(p_, l), feats),
+                        ("fusion", lambda p_, l: O_heads.cross_attention_fusion(p_, l[0], l[1])[0], [a, b])):
+        p_ = {k: v.detach().clone().requires_grad_(True) for k, v in mods[nm].state_dict().items()}
+        out = fn(p_, ins)
+        (out * enc[f"{nm}_cot0"]).sum().backward()
+        for k, gr in pg[nm].items():
+            close(p_[k].grad, gr, tol=2e-5, what=f"oracle grad {nm}.{k}")
+    enc.update({f"pg_{nm}": d for nm, d in pg.items()})
     targets = {"Y": (torch.rand(B, generator=g) < 0.3).float(), "Y_pKd": torch.randn(B, generator=g) + 6,
                "Y_pKi": torch.randn(B, generator=g) + 6, "Y_KIBA": torch.randn(B, generator=g) + 11}
     masks = {"Y_pKd": torch.tensor([1, 0, 1, 1, 0, 0]).bool(), "Y_pKi": torch.zeros(B).bool(), "Y_KIBA": torch.tensor([0, 1, 1, 0, 1, 1]).bool()}
@@ -507,13 +539,261 @@ def gen_full_steps():
     npz("common_step", **rec2)
 
 
+# =============================================================================== validation ELBO step, sampling trajectory
+def _record_extra_features(model):
+    """Wraps model.get_extra_features so that every call's outputs are kept (eigenvector columns are gauge dependent:
+    a replay must inject them)."""
+    calls = []
+    orig = model.get_extra_features
+
+    def wrapped(*a, **k):
+        out = orig(*a, **k)
+        calls.append((out[0].detach().clone(), out[1].detach().clone()))
+        return out
+
+    model.get_extra_features = wrapped
+    return calls
+
+
+def gen_val_step():
+    model, kw, infos = make_full_model(phase="pretrain_drug", seed=3)
+    model.eval()
+    mx = torch.tensor(infos["dataset"]["node_marginals"]); me = torch.tensor(infos["dataset"]["edge_marginals"])
+    g = torch.Generator().manual_seed(71)
+    bs, n, cx, ce = 4, 9, 8, 5
+    X, E, mask = ragged_graph(bs, n, [9, 7, 5, 3], cx, ce, g)
+    feats = {"FP-Morgan": (torch.rand(bs, 64, generator=g) < 0.15).float(), "EMB-BiomedGraph": torch.randn(bs, 24, generator=g)}
+    batch = {"id": torch.arange(bs), "features": feats, "representations": {"smiles": ["C"] * bs}, "G": None}
+    dc = ref.dc
+    model._extract_graph_data = lambda b: dc.GraphData(X=X.clone(), E=E.clone(), node_mask=mask)
+    calls = _record_extra_features(model)
+    probs = {}
+    orig_logp = model.reconstruction_logp
+
+    def logp(*a, **k):
+        out = orig_logp(*a, **k)
+        probs["X"], probs["E"] = out[0].detach().clone(), out[1].detach().clone()
+        return out
+
+    model.reconstruction_logp = logp
+    torch.manual_seed(70)
+    with torch.no_grad():
+        bd, ed, pdta, ld = model._common_step(batch, "val")
+    total = ld.compute_loss(model.weights)
+    # the same RNG stream, drawn by hand: t, Exp(1) X / E, lcc noise, eps, then the t = 0 sample's Exp(1) X / E and lcc noise
+    torch.manual_seed(70)
+    t_int = torch.randint(1, 501, size=(bs, 1)).float()
+    eX = torch.empty(bs * n, cx).exponential_(1); eE = torch.empty(bs * n * n, ce).exponential_(1)
+    lcc = torch.randn(bs, n)
+    eps = torch.randn(bs, 32)
+    eX0 = torch.empty(bs * n, cx).exponential_(1); eE0 = torch.empty(bs * n * n, ce).exponential_(1)
+    lcc0 = torch.randn(bs, n)
+    gd = bd.graph_data
+    assert torch.equal(t_int, gd.noise_params["t_int"]) and len(calls) == 2
+    close(ed.drug_mu + eps * torch.exp(0.5 * ed.drug_logvar), ed.drug_embedding, what="eps replay (val)")
+    # oracle restatement of the whole estimator on the same draws (eigenvector features injected from the reference)
+    sch = O_dif.Schedule(500)
+    gen_ = infos["general"]
+    dec_sd = {k[len("drug_decoder."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("drug_decoder.")}
+    gtk = kw["graph_transformer_kwargs"]
+    oXt, oEt, onp, _, _ = O_dif.apply_noise(sch, mx, me, X, E, mask, t_int, eX, eE)
+    assert torch.equal(oXt, gd.X_t.float()) and torch.equal(oEt, gd.E_t.float())
+
+    def o_denoise(Xn, En, tt, noise, ref_extra, trunc=False):
+        Xe, ye = O_feat.extra_features(Xn, En, tt, mask, noise, gen_["max_n_nodes"], gen_["atom_valencies"], gen_["atom_weights"],
+                                       gen_["max_weight"], truncate_weight=trunc)
+        close(Xe[..., :4], ref_extra[0][..., :4], what="val X_extra"); close(ye, ref_extra[1], what="val y_extra")
+        Xe = torch.cat((Xe[..., :4], ref_extra[0][..., 4:6], Xe[..., 6:]), -1)
+        oX, oE, _ = O_den.graph_transformer(dec_sd, torch.cat([Xn, Xe], 2), En, torch.cat([ed.drug_embedding, ye], 1), mask,
+                                            gtk["n_layers"], gtk["hidden_dims"]["n_head"], gtk["output_dims"])
+        return oX, oE
+
+    with torch.no_grad():
+        lX, lE = o_denoise(oXt, oEt, onp["t"], lcc, calls[0], trunc=True)       # (apply_noise hands over int64 one-hots)
+        close(lX, pdta.graph_reconstruction.X, tol=2e-5, what="val logits X"); close(lE, pdta.graph_reconstruction.E, tol=2e-5, what="val logits E")
+        pX0, pE0, X0s, E0s = O_dif.reconstruction_probs(sch, mx, me, X, E, mask, eX0, eE0,
+                                                        lambda a, b, t0: o_denoise(a, b, t0, lcc0, calls[1]))
+        close(pX0, probs["X"], tol=2e-5, what="probX0"); close(pE0, probs["E"], tol=2e-5, what="probE0")
+        nll, parts = O_dif.val_nll(sch, mx, me, model.nodes_dist.prob, X, E, oXt, oEt, lX, lE, mask, onp, pX0, pE0)
+    close(nll, ld.reconstruction, tol=2e-5, what="val NLL")
+    close(parts["loss_term_0"], ld.components["loss_term_0"], tol=2e-5, what="loss_term_0")
+    close(parts["kl_prior"].mean(), ld.components["kl prior"], what="kl prior"); close(parts["log_pN"].mean(), ld.components["log_pn"], what="log pN")
+    sd = {k: v for k, v in model.state_dict().items()}
+    npz("val_step", sd=sd, X=X, E=E, mask=mask, feat=feats, t_int=t_int, expX=eX, expE=eE, lcc_noise=lcc, eps=eps,
+        expX0=eX0, expE0=eE0, lcc_noise0=lcc0, X_extra=calls[0][0], y_extra=calls[0][1], X_extra0=calls[1][0], y_extra0=calls[1][1],
+        X_t=gd.X_t.float(), E_t=gd.E_t.float(), pred_X=pdta.graph_reconstruction.X, pred_E=pdta.graph_reconstruction.E,
+        probX0=probs["X"], probE0=probs["E"], nll=ld.reconstruction, kl_prior=ld.components["kl prior"],
+        Lt=ld.components["Estimator loss terms"], log_pn=ld.components["log_pn"], loss_term_0=ld.components["loss_term_0"],
+        loss_total=total, loss_complexity=ld.complexity, loss_contrastive=ld.contrastive,
+        epoch_NLL=model.val_nll.compute(), epoch_X_kl=model.val_X_kl.compute() * model.T, epoch_E_kl=model.val_E_kl.compute() * model.T,
+        epoch_X_logp=model.val_X_logp.compute(), epoch_E_logp=model.val_E_logp.compute(),
+        mx=mx, me=me, weights=torch.tensor(model.weights))
+
+
+def gen_trajectory():
+    """Five reverse steps of sample_batch (T = 5), every step's collapsed class ids; the loop of the reference's
+    sample_batch (full.py:997-1027) is restated here around its own sample_discrete_feature_noise / sample_p_zs_given_zt so
+    that the per-step random draws and eigenvector features can be recorded."""
+    T = 5
+    model, kw, infos = make_full_model(phase="pretrain_drug", seed=4, T=T)
+    model.eval()
+    mx = torch.tensor(infos["dataset"]["node_marginals"]); me = torch.tensor(infos["dataset"]["edge_marginals"])
+    g = torch.Generator().manual_seed(81)
+    n_nodes = torch.tensor([9, 4, 6, 7, 2])
+    bs, n, cx, ce = 5, 9, 8, 5
+    emb = torch.randn(bs, 32, generator=g)
+    mask = torch.arange(n).unsqueeze(0) < n_nodes.unsqueeze(1)
+    calls = _record_extra_features(model)
+    torch.manual_seed(80)
+    with torch.no_grad():
+        zT = ref.dutils.sample_discrete_feature_noise(limit_dist=model.limit_dist, node_mask=mask)
+        Xr, Er = zT.X, zT.E
+        traj = []
+        for s_int in reversed(range(T)):
+            s_arr = s_int * torch.ones((bs, 1))
+            z = model.sample_p_zs_given_zt(s_arr / T, (s_arr + 1) / T, Xr, Er, emb, mask)
+            Xr, Er = z.X, z.E
+            c = ref.dutils.PlaceHolder(X=Xr.clone(), E=Er.clone(), y=None).mask(mask, collapse=True)
+            traj.append((c.X.clone(), c.E.clone()))
+    # replay of the RNG stream + oracle restatement
+    torch.manual_seed(80)
+    eXs, eEs, lccs = [], [], []
+    eXs.append(torch.empty(bs * n, cx).exponential_(1)); eEs.append(torch.empty(bs * n * n, ce).exponential_(1))
+    sch = O_dif.Schedule(T)
+    gen_ = infos["general"]
+    dec_sd = {k[len("drug_decoder."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("drug_decoder.")}
+    gtk = kw["graph_transformer_kwargs"]
+    Xo, Eo = O_dif.sample_limit(mx, me, mask, eXs[0], eEs[0])
+    assert torch.equal(Xo, zT.X) and torch.equal(Eo, zT.E)
+    with torch.no_grad():
+        for k, s_int in enumerate(reversed(range(T))):
+            lccs.append(torch.randn(bs, n))
+            eXs.append(torch.empty(bs * n, cx).exponential_(1)); eEs.append(torch.empty(bs * n * n, ce).exponential_(1))
+            s = torch.full((bs, 1), float(s_int)) / T; t = torch.full((bs, 1), float(s_int + 1)) / T
+            Xe, ye = O_feat.extra_features(Xo, Eo, t, mask, lccs[-1], gen_["max_n_nodes"], gen_["atom_valencies"], gen_["atom_weights"],
+                                           gen_["max_weight"])
+            close(ye, calls[k][1], what=f"traj y_extra {k}")
+            Xe = torch.cat((Xe[..., :4], calls[k][0][..., 4:6], Xe[..., 6:]), -1)
+            oX, oE, _ = O_den.graph_transformer(dec_sd, torch.cat([Xo, Xe], 2), Eo, torch.cat([emb, ye], 1), mask,
+                                                gtk["n_layers"], gtk["hidden_dims"]["n_head"], gtk["output_dims"])
+            pX, pE = O_dif.reverse_step_probs(oX, oE, Xo, Eo, sch.beta(t_normalized=t), sch.alpha_bar(t_normalized=s),
+                                              sch.alpha_bar(t_normalized=t), mx, me)
+            Xc, Ec = O_dif.sample_graph(pX, pE, mask, eXs[-1], eEs[-1])
+            Xo, Eo = O_dif.one_hot_masked(Xc, Ec, mask, cx, ce)
+            cX = torch.where(mask, Xc, torch.full_like(Xc, -1))
+            cE = torch.where(mask.unsqueeze(1) & mask.unsqueeze(2), Ec, torch.full_like(Ec, -1))
+            assert torch.equal(cX, traj[k][0]) and torch.equal(cE, traj[k][1]), f"trajectory step {k}: oracle != reference"
+    sd = {k: v for k, v in model.state_dict().items()}
+    rec = dict(sd=sd, emb=emb, n_nodes=n_nodes, mask=mask, mx=mx, me=me, T=torch.tensor(T), z_T_X=zT.X, z_T_E=zT.E)
+    for k in range(T + 1):
+        rec[f"expX_{k}"], rec[f"expE_{k}"] = eXs[k], eEs[k]
+    for k in range(T):
+        rec[f"lcc_{k}"], rec[f"eigvec_{k}"] = lccs[k], calls[k][0][..., 4:6]
+        rec[f"traj_X_{k}"], rec[f"traj_E_{k}"] = traj[k]
+    npz("trajectory", **rec)
+
+
+# =============================================================================== non-diffusion model variants
+def gen_variants():
+    import mb_vae_dti.training.modules.baseline as m_base
+    import mb_vae_dti.training.modules.multi_modal as m_modal
+    import mb_vae_dti.training.modules.multi_output as m_out
+    import mb_vae_dti.training.modules.multi_hybrid as m_hyb
+    torch.set_float32_matmul_precision("highest")
+    g = torch.Generator().manual_seed(90)
+    B = 6
+    feats_d = {"FP-Morgan": (torch.rand(B, 64, generator=g) < 0.15).float(), "EMB-BiomedGraph": torch.randn(B, 24, generator=g),
+               "EMB-BiomedText": torch.randn(B, 20, generator=g)}
+    feats_t = {"FP-ESP": (torch.rand(B, 48, generator=g) < 0.15).float(), "EMB-ESM": torch.randn(B, 40, generator=g)}
+    ydict = {"Y": (torch.rand(B, generator=g) < 0.4).float(), "Y_pKd": torch.randn(B, generator=g) + 6, "Y_pKi": torch.randn(B, generator=g) + 6,
+             "Y_KIBA": torch.randn(B, generator=g) + 11, "Y_pKd_mask": torch.tensor([True, False, True, True, False, True]),
+             "Y_pKi_mask": torch.tensor([False, True, False, True, False, False]), "Y_KIBA_mask": torch.tensor([True, True, False, False, True, True])}
+    batch = {"id": torch.arange(B), "y": {k: v.clone() for k, v in ydict.items()},
+             "drug": {"features": feats_d, "representations": {"smiles": ["C"] * B}}, "target": {"features": feats_t}}
+    common = dict(learning_rate=1e-3, weight_decay=1e-4, scheduler="const", embedding_dim=32, hidden_dim=16, factor=4, n_layers=2,
+                  activation="relu", dropout=0.1, bias=True)
+    cases = {
+        "baseline": (m_base.BaselineDTIModel, dict(phase="finetune", finetune_score="Y_pKd", drug_features={"FP-Morgan": 64},
+                                                   target_features={"FP-ESP": 48}, encoder_type="transformer", **common)),
+        "baseline_resnet": (m_base.BaselineDTIModel, dict(phase="finetune", finetune_score="Y_KIBA", drug_features={"FP-Morgan": 64},
+                                                          target_features={"FP-ESP": 48}, encoder_type="resnet", **common)),
+        "multi_modal": (m_modal.MultiModalDTIModel, dict(phase="finetune", finetune_score="Y_pKd",
+                                                         drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 24, "EMB-BiomedText": 20},
+                                                         target_features={"FP-ESP": 48, "EMB-ESM": 40}, encoder_type="resnet",
+                                                         aggregator_type="concat", **common)),
+        "multi_output": (m_out.MultiOutputDTIModel, dict(phase="train", finetune_score=None, drug_features={"FP-Morgan": 64},
+                                                         target_features={"FP-ESP": 48}, encoder_type="transformer",
+                                                         dti_weights=[1.0, 0.903964, 0.282992, 0.755172], **common)),
+        "multi_hybrid": (m_hyb.MultiHybridDTIModel, dict(phase="train", finetune_score=None, weights=[1.0, 0.0, 0.5, 0.0],
+                                                         dti_weights=[1.0, 0.903964, 0.282992, 0.755172], contrastive_temp=0.1,
+                                                         drug_features={"FP-Morgan": 64, "EMB-BiomedGraph": 24, "EMB-BiomedText": 20},
+                                                         target_features={"FP-ESP": 48, "EMB-ESM": 40}, encoder_type="resnet",
+                                                         aggregator_type="concat", **common)),
+    }
+    rec = dict(feat_d=feats_d, feat_t=feats_t, y=ydict)
+    for seed, (name, (cls, kw)) in enumerate(cases.items()):
+        torch.manual_seed(100 + seed)
+        model = cls(**kw).eval()
+        b = {"id": batch["id"], "y": {k: v.clone() for k, v in ydict.items()}, "drug": batch["drug"], "target": batch["target"]}
+        bd, ed, pdta, ld = model._common_step(b)
+        total = ld.compute_loss(model.weights) if hasattr(model, "weights") else ld.accuracy
+        total.backward()
+        rec[f"{name}_sd"] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        rec[f"{name}_grad"] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        rec[f"{name}_loss"] = total.detach()
+        rec[f"{name}_drug_embedding"] = ed.drug_embedding.detach()
+        rec[f"{name}_target_embedding"] = ed.target_embedding.detach()
+        if ed.fused_embedding is not None:
+            rec[f"{name}_fused"] = ed.fused_embedding.detach()
+        sc = pdta.dti_scores
+        if isinstance(sc, dict):
+            for k, v in sc.items():
+                rec[f"{name}_score_{k}"] = v.detach()
+        else:
+            rec[f"{name}_score"] = sc.detach()
+        if ld.contrastive is not None:
+            rec[f"{name}_contrastive"] = ld.contrastive.detach()
+        # oracle: encoders / aggregators / fusion / heads composed by hand
+        sd = model.state_dict()
+
+        def sub(prefix):
+            return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+        enc_fn = O_heads.residual_encoder if kw["encoder_type"] == "resnet" else O_heads.transformer_encoder
+        if name.startswith("baseline") or name == "multi_output":
+            od = enc_fn(sub("drug_encoder."), feats_d["FP-Morgan"]); ot = enc_fn(sub("target_encoder."), feats_t["FP-ESP"])
+        else:
+            od = O_heads.concat_aggregator(sub("drug_aggregator."), [enc_fn(sub(f"drug_encoders.{k}."), feats_d[k]) for k in kw["drug_features"]])
+            ot = O_heads.concat_aggregator(sub("target_aggregator."), [enc_fn(sub(f"target_encoders.{k}."), feats_t[k]) for k in kw["target_features"]])
+        close(od, ed.drug_embedding, what=name + " drug embedding"); close(ot, ed.target_embedding, what=name + " target embedding")
+        if name.startswith("baseline") or name == "multi_modal":
+            key = kw["finetune_score"]; m = ydict[key + "_mask"]
+            close(F.mse_loss((od * ot).sum(-1)[m], ydict[key][m]), total, what=name + " loss")
+        else:
+            fused, _ = O_heads.cross_attention_fusion(sub("fusion."), od, ot)
+            scores = O_heads.dti_head(sub("dti_head."), fused)
+            acc, _ = O_heads.dti_accuracy_loss(scores, {k: ydict[k] for k in ("Y", "Y_pKd", "Y_pKi", "Y_KIBA")},
+                                               {k: ydict[k + "_mask"] for k in ("Y_pKd", "Y_pKi", "Y_KIBA")}, kw["dti_weights"])
+            if name == "multi_hybrid":
+                con = (O_heads.info_nce(sub("drug_contrastive_head."), od, feats_d["FP-Morgan"], 0.1)
+                       + O_heads.info_nce(sub("target_contrastive_head."), ot, feats_t["FP-ESP"], 0.1))
+                close(acc + 0.5 * con, total, what=name + " loss")
+            else:
+                close(acc, total, what=name + " loss")
+    npz("variants", **rec)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_schedule()
-    model, infos, X, E, mask, rec = gen_noise()
-    gen_features(model, infos, X, E, mask, rec)
-    gen_denoiser()
-    gen_heads()
-    gen_posterior(model, infos, X, E, mask, rec)
-    gen_full_steps()
+    if "--only-new" not in sys.argv:
+        gen_schedule()
+        model, infos, X, E, mask, rec = gen_noise()
+        gen_features(model, infos, X, E, mask, rec)
+        gen_denoiser()
+        gen_heads()
+        gen_posterior(model, infos, X, E, mask, rec)
+        gen_full_steps()
+    gen_val_step()
+    gen_trajectory()
+    gen_variants()
     print("all fixtures written and oracle == reference on every one")
