@@ -76,9 +76,10 @@ inline int mbvae_num_cus() {
   return c;
 }
 
-// Raises `kernel`'s dynamic-LDS limit to the device maximum once per device (the attribute is a cap, not an
-// allocation).  One static flag word per call site; evaluates to false if the runtime call fails.
-#define MBVAE_LDS_LIMIT 163840          /* 160 KB per workgroup on gfx950 */
+// Raises `kernel`'s dynamic-LDS limit once per device (the attribute is a cap, not an allocation) to 152 KB: the
+// 160 KB a workgroup can have on gfx950 minus room for the kernels' small static __shared__ variables, which count
+// against the same total.  One static flag word per call site; evaluates to false if the runtime call fails.
+#define MBVAE_LDS_LIMIT 155648
 #define MBVAE_ALLOW_BIG_LDS(kernel)                                                                                   \
   ([&]() -> bool {                                                                                                    \
     static std::atomic<unsigned long long> done_{0ull};                                                               \

@@ -620,7 +620,8 @@ def test_elbo_terms_golden():
     bd = BatchData(graph_data=gd)
     pred = PredictionData(graph_reconstruction=PlaceHolder(X=g["logits_X"].cuda(), E=g["logits_E"].cuda()))
     with torch.no_grad():
-        assert_close(model.kl_prior(bd), g["kl_prior"], what="kl_prior")
+        # ~alpha_bar_T^2 ~ 1e-7 per graph: both sides hold the rounding of ~400 differences of O(1) logs (absolute bound)
+        assert_close(model.kl_prior(bd), g["kl_prior"], atol=2e-6, what="kl_prior")
         assert_close(model.compute_Lt(bd, pred), g["Lt"], rtol=2e-5, what="Lt")
 
 

@@ -127,7 +127,7 @@ def test_model_variants_common_step_golden(name):
     assert set(g[name + "_grad"]) == {k for k, p in params.items() if p.grad is not None}
     for k, v in g[name + "_grad"].items():
         # whole-network gradients: chains of <= 12 products with reductions of <= 64 terms; 3e-5 of the tensor's scale
-        assert_close(params[k].grad, v, rtol=3e-5, what="grad " + k)
+        assert_close(params[k].grad, v, rtol=3e-5, atol=1e-6 if _is_null_grad(k) else None, what="grad " + k)
     # the Lightning-style steps return the same loss and log it
     model.zero_grad()
     batch["y"] = {k: (v.bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
@@ -213,7 +213,9 @@ def test_validation_step_elbo_golden():
     assert_close(out.X, g["pred_X"], rtol=2e-5, what="logits X"); assert_close(out.E, g["pred_E"], rtol=2e-5, what="logits E")
     assert_close(seen["X"], g["probX0"], rtol=2e-5, what="probX0"); assert_close(seen["E"], g["probE0"], rtol=2e-5, what="probE0")
     parts = loss.components
-    assert_close(parts["kl prior"], g["kl_prior"], what="KL prior"); assert_close(parts["log_pn"], g["log_pn"], what="log p(N)")
+    # KL(q(z_T | x) || limit) is ~alpha_bar_T^2 ~ 1e-7 at T = 500: what both sides hold is the rounding of ~400 differences
+    # of O(1) log-probabilities, compared absolutely
+    assert_close(parts["kl prior"], g["kl_prior"], atol=2e-6, what="KL prior"); assert_close(parts["log_pn"], g["log_pn"], what="log p(N)")
     # T * KL and the t = 0 term sum ~400 log-probabilities each: 2e-5 of their value
     assert_close(parts["Estimator loss terms"], g["Lt"], rtol=2e-5, what="T * KL"); assert_close(parts["loss_term_0"], g["loss_term_0"], rtol=2e-5, what="t = 0 term")
     assert_close(loss.reconstruction, g["nll"], rtol=2e-5, what="NLL")
