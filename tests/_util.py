@@ -33,5 +33,13 @@ def assert_close(a, b, rtol=1e-5, atol=None, what=""):
     assert bool(torch.isfinite(a).all()), f"{what}: non-finite values"
     scale = float(b.abs().max()) if b.numel() else 0.0
     err = float((a - b).abs().max()) if b.numel() else 0.0
+    cap = os.environ.get("MBVAE_TEST_RTOL_CAP")          # survey aid: which checks need more than a given bound
+    if cap:
+        rtol = min(rtol, float(cap))
     tol = rtol * scale if atol is None else atol
+    report = os.environ.get("MBVAE_TEST_REPORT")         # survey aid: one line per check with its relative error
+    if report:
+        with open(report, "a") as f:
+            f.write(f"{err / max(scale, 1e-300):.3e}\t{rtol:.1e}\t{'abs' if atol is not None else 'rel'}\t"
+                    f"{os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]}\t{what}\n")
     assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e}, rel {err / max(scale, 1e-300):.2e})"

@@ -1,7 +1,8 @@
 """GPU parity: every HIP kernel, through the C ABI, against the CPU oracle and the golden fixtures.
 
-Tolerance: fp32 results within 1e-5 of the tensor's scale (max|ref|, at least 1); class ids, masks and
-one-hot samples bit-exact.
+Tolerance: fp32 results within 1e-5 of the reference tensor's largest magnitude (no floor on that scale; measured
+errors are <= 3.2e-6 everywhere, see tests/_util.py for how to list them); class ids, masks and one-hot samples
+bit-exact.  The few checks with another bound say why next to it.
 """
 import math
 
@@ -67,8 +68,8 @@ def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     (yg * cot.cuda()).sum().backward()
     assert_close(yg, y, what="y")
     assert_close(xg.grad, xr.grad, what="dx")
-    assert_close(wg.grad, wr.grad, rtol=2e-5, what="dw")
-    assert_close(bg.grad, br.grad, rtol=2e-5, what="db")
+    assert_close(wg.grad, wr.grad, what="dw")
+    assert_close(bg.grad, br.grad, what="db")
 
 
 def test_linear_relu_dropout_statistics(ops):
@@ -115,7 +116,7 @@ def test_edge_attention(ops, bs, n, dx, H):
     assert_close(Pg, P, what="P"); assert_close(wVg, wV, what="wV")
     got = list(QKV.grad.split(dx, -1)) + list(E12.grad.split(dx, -1)) + [yag.grad, ymg.grad]
     for name, a, b in zip(("dQ", "dK", "dV", "dE1", "dE2", "dye_add", "dye_mul"), got, cpu):
-        assert_close(a, b.grad, rtol=2e-5, what=name)
+        assert_close(a, b.grad, what=name)
 
 
 # ------------------------------------------------------------------------------------------------ residual + LayerNorm
@@ -133,7 +134,7 @@ def test_ln_residual(ops, rows, D):
     (yg * cot.cuda()).sum().backward()
     assert_close(yg, y, what="y")
     for name, a, b in zip(("dx", "dr", "dgamma", "dbeta"), q, c):
-        assert_close(a.grad, b.grad, rtol=2e-5, what=name)
+        assert_close(a.grad, b.grad, what=name)
     # r = None path
     y2 = ops.ln_residual(q[0].detach(), None, q[2].detach(), q[3].detach(), 1e-5)
     assert_close(y2, F.layer_norm(x, (D,), gamma, beta, 1e-5), what="plain LN")
@@ -170,7 +171,7 @@ def test_pool_stats(ops, shape):
     sg = ops.pool_stats(xg)
     (sg * cot.cuda()).sum().backward()
     assert_close(sg, s, what="stats")
-    assert_close(xg.grad, xr.grad, rtol=2e-5, what="dx")
+    assert_close(xg.grad, xr.grad, what="dx")
 
 
 # ------------------------------------------------------------------------------------------------ symmetrise + mask
@@ -308,7 +309,7 @@ def test_masks_select_not_multiply_nan_poisoned_memory(ops):
         net.requires_grad_(True)
         for a, b, nm in ((frozen.X, ref.X, "X"), (frozen.E, ref.E, "E"), (frozen.y, ref.y, "y")):
             assert bool(torch.isfinite(a).all()), f"n={n}: non-finite {nm} with frozen weights"
-            assert_close(a, b.detach(), rtol=2e-5, what=f"n={n} frozen-weight forward {nm}")
+            assert_close(a, b.detach(), what=f"n={n} frozen-weight forward {nm}")
         with torch.no_grad():
             net(Xin, E0, yin, mask)                                     # first sight of the mask
             poison()
@@ -316,7 +317,7 @@ def test_masks_select_not_multiply_nan_poisoned_memory(ops):
         assert net._pad_cache["order"] is not None and net._pad_cache["order"].sparse == (n <= 64)
         for a, b, nm in ((again.X, ref.X, "X"), (again.E, ref.E, "E"), (again.y, ref.y, "y")):
             assert bool(torch.isfinite(a).all()), f"n={n}: non-finite {nm} on the inference path"
-            assert_close(a, b.detach(), rtol=2e-5, what=f"n={n} inference forward {nm}")
+            assert_close(a, b.detach(), what=f"n={n} inference forward {nm}")
 
 
 def test_dropout_masks_agree_between_forward_and_backward_at_edge_widths(ops):
@@ -338,8 +339,8 @@ def test_dropout_masks_agree_between_forward_and_backward_at_edge_widths(ops):
     (y * cot).sum().backward()
     xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
     (ops.linear(xr, wr, br, act=1) * keep / (1 - p) * cot).sum().backward()
-    assert_close(x.grad, xr.grad, what="dx under dropout"); assert_close(w.grad, wr.grad, rtol=2e-5, what="dw under dropout")
-    assert_close(b.grad, br.grad, rtol=2e-5, what="db under dropout")
+    assert_close(x.grad, xr.grad, what="dx under dropout"); assert_close(w.grad, wr.grad, what="dw under dropout")
+    assert_close(b.grad, br.grad, what="db under dropout")
     # residual dropout in front of the LayerNorm
     xe, r = torch.randn(M, 64, generator=g).cuda().requires_grad_(True), torch.randn(M, 64, generator=g).cuda().requires_grad_(True)
     gamma, beta = (1 + 0.1 * torch.randn(64, generator=g)).cuda(), torch.zeros(64).cuda()
@@ -389,10 +390,10 @@ def test_denoiser_tiny_forward_backward_golden():
     out = net(X, E, y, g["mask"].bool().cuda())
     assert_close(out.X, g["out_X"], what="X"); assert_close(out.E, g["out_E"], what="E"); assert_close(out.y, g["out_y"], what="y")
     ((out.X * g["cX"].cuda()).sum() + (out.E * g["cE"].cuda()).sum() + (out.y * g["cy"].cuda()).sum()).backward()
-    assert_close(X.grad, g["dX"], rtol=2e-5, what="dX"); assert_close(E.grad, g["dE"], rtol=2e-5, what="dE")
-    assert_close(y.grad, g["dy"], rtol=2e-5, what="dy")
+    assert_close(X.grad, g["dX"], what="dX"); assert_close(E.grad, g["dE"], what="dE")
+    assert_close(y.grad, g["dy"], what="dy")
     for k, p in net.named_parameters():
-        assert_close(p.grad, g["grad"][k], rtol=3e-5, what="grad " + k)
+        assert_close(p.grad, g["grad"][k], what="grad " + k)
 
 
 def test_layer_tiny_golden():
@@ -422,7 +423,7 @@ def test_denoiser_realwidth_golden():
     with torch.no_grad():
         out = net(g["X"].cuda(), g["E"].cuda(), g["y"].cuda(), g["mask"].bool().cuda())
     assert_close(out.X, g["out_X"], what="X"); assert_close(out.E, g["out_E"], what="E")
-    assert_close(out.y, g["out_y"], rtol=2e-5, what="y")
+    assert_close(out.y, g["out_y"], what="y")
 
 
 # ------------------------------------------------------------------------------------------------ eigensolver + features
@@ -535,7 +536,7 @@ def test_full_model_common_step_golden():
     # eigenvector input features are gauge dependent (sign): inject the reference's and compare the decoder exactly
     bd.graph_data.X_extra = g["X_extra"].cuda()
     out = model.denoise_drug_graph(emb, bd)
-    assert_close(out.X, g["pred_X"], rtol=2e-5, what="pred X"); assert_close(out.E, g["pred_E"], rtol=2e-5, what="pred E")
+    assert_close(out.X, g["pred_X"], what="pred X"); assert_close(out.E, g["pred_E"], what="pred E")
     rec = model.reconstruction_head(out.X, out.E, bd.graph_data.X, bd.graph_data.E)
     assert_close(rec, g["loss_reconstruction"], what="reconstruction")
     loss.reconstruction = rec
@@ -543,11 +544,11 @@ def test_full_model_common_step_golden():
     assert_close(total, g["loss_total"], what="total")
     total.backward()
     for k, v in g["grad"].items():
-        assert_close(dict(model.named_parameters())[k].grad, v, rtol=5e-5, what="grad " + k)
+        assert_close(dict(model.named_parameters())[k].grad, v, what="grad " + k)
     for k, v in g["gradnorm"].items():
         got = dict(model.named_parameters())[k].grad
         assert got is not None, k
-        assert abs(float(got.norm()) - float(v)) <= 1e-4 * max(1.0, float(v)), f"grad norm {k}: {float(got.norm())} vs {float(v)}"
+        assert abs(float(got.norm()) - float(v)) <= 1e-5 * float(v), f"grad norm {k}: {float(got.norm())} vs {float(v)}"
 
 
 def test_full_model_sampling_and_val_step_run():
@@ -622,7 +623,7 @@ def test_elbo_terms_golden():
     with torch.no_grad():
         # ~alpha_bar_T^2 ~ 1e-7 per graph: both sides hold the rounding of ~400 differences of O(1) logs (absolute bound)
         assert_close(model.kl_prior(bd), g["kl_prior"], atol=2e-6, what="kl_prior")
-        assert_close(model.compute_Lt(bd, pred), g["Lt"], rtol=2e-5, what="Lt")
+        assert_close(model.compute_Lt(bd, pred), g["Lt"], what="Lt")
 
 
 def test_conditional_generator_batched_optimisation_matches_per_latent_loop():
@@ -723,13 +724,13 @@ def test_denoiser_full_size_properties():
         Xp = X[bi, perm]
         Ep = E0[bi.unsqueeze(2), perm.unsqueeze(2), perm.unsqueeze(1)]
         outp = net(Xp, Ep, y, mask)
-        assert_close(outp.X, out.X[bi, perm], rtol=5e-5, what="permuted X")
-        assert_close(outp.E, out.E[bi.unsqueeze(2), perm.unsqueeze(2), perm.unsqueeze(1)], rtol=5e-5, what="permuted E")
-        assert_close(outp.y, out.y, rtol=5e-5, what="permuted y")
+        assert_close(outp.X, out.X[bi, perm], what="permuted X")
+        assert_close(outp.E, out.E[bi.unsqueeze(2), perm.unsqueeze(2), perm.unsqueeze(1)], what="permuted E")
+        assert_close(outp.y, out.y, what="permuted y")
         # batch independence: the first 9 graphs alone (36 864 edge rows, still on the persistent kernels)
         sub = net(X[:9], E0[:9], y[:9], mask[:9])
-        assert_close(sub.X, out.X[:9], rtol=2e-5, what="sub-batch X"); assert_close(sub.E, out.E[:9], rtol=2e-5, what="sub-batch E")
-        assert_close(sub.y, out.y[:9], rtol=2e-5, what="sub-batch y")
+        assert_close(sub.X, out.X[:9], what="sub-batch X"); assert_close(sub.E, out.E[:9], what="sub-batch E")
+        assert_close(sub.y, out.y[:9], what="sub-batch y")
 
 
 @pytest.mark.parametrize("bs,n,de,N", [(16, 64, 64, 512), (3, 9, 16, 64)])
@@ -752,8 +753,8 @@ def test_edge_input_fanout(ops, bs, n, de, N):
     yg, sg, alias = ops.edge_input(Eg, wg, bg, mask.cuda(), n)
     ((yg * c1.cuda()).sum() + (sg * c2.cuda()).sum() + (alias * c3.cuda()).sum()).backward()
     assert_close(yg, y, what="projection"); assert_close(sg, stats, what="pool stats"); assert torch.equal(alias, Eg)
-    assert_close(Eg.grad, Er.grad, rtol=2e-5, what="dE"); assert_close(wg.grad, wr.grad, rtol=2e-5, what="dw")
-    assert_close(bg.grad, br.grad, rtol=2e-5, what="db")
+    assert_close(Eg.grad, Er.grad, what="dE"); assert_close(wg.grad, wr.grad, what="dw")
+    assert_close(bg.grad, br.grad, what="db")
 
 
 def _edge_block_reference(E, w12, b12, QKV, ya, ym, mask, n_head):
@@ -806,7 +807,7 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
     vm = xm.bool().expand(-1, -1, dx)
     assert_close(P, Pr, what="P"); assert_close(wV * xm.cuda(), Wr * xm, what="wV"); assert_close(stats, Sr, what="stats")
     for got, t, name in zip(grads, ref_in, ("dE", "dw12", "db12", "dQKV", "dye_add", "dye_mul")):
-        assert_close(got, t.grad, rtol=3e-5, what=name)
+        assert_close(got, t.grad, what=name)
     P0, wV0, _, _ = run(False)        # inference: no projection output is written at all, P only on valid pairs
     pm = (mask.unsqueeze(1) & mask.unsqueeze(2)).cuda()
     assert torch.equal(P0[pm], P[pm]) and torch.equal(wV0 * xm.cuda(), wV * xm.cuda())
@@ -996,11 +997,11 @@ def test_denoiser_inference_padding_shortcuts_are_exact():
     assert torch.equal(a.E, a1.E)
     assert net._pad_cache["order"] is not None and net._pad_cache["order"].sparse and net._pad_cache["pack"] is not None
     # the sparse order pools the padding pairs analytically: same mathematics, different rounding
-    assert_close(a2.X, a.X, rtol=2e-5, what="X (sparse order)"); assert_close(a2.E, a.E, rtol=2e-5, what="E (sparse order)")
-    assert_close(a2.y, a.y, rtol=2e-5, what="y (sparse order)")
+    assert_close(a2.X, a.X, what="X (sparse order)"); assert_close(a2.E, a.E, what="E (sparse order)")
+    assert_close(a2.y, a.y, what="y (sparse order)")
     c = net(Xin, E0, yin, mask)                      # gradients enabled: training-form kernels
-    assert_close(a.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(a.E, c.E.detach(), rtol=2e-5, what="E")
-    assert_close(a.y, c.y.detach(), rtol=2e-5, what="y")
+    assert_close(a.X, c.X.detach(), what="X"); assert_close(a.E, c.E.detach(), what="E")
+    assert_close(a.y, c.y.detach(), what="y")
 
 
 def test_packed_node_rows(ops):
@@ -1050,9 +1051,9 @@ def test_packed_node_rows(ops):
         b2 = net(Xb, Eb, yin[:2], big)
     assert net._pad_cache["order"] is not None and net._pad_cache["pack"] is None
     c2 = net(Xb, Eb, yin[:2], big)
-    assert_close(b2.X, c2.X.detach(), rtol=2e-5, what="X, n = 70"); assert_close(b2.E, c2.E.detach(), rtol=2e-5, what="E, n = 70")
-    assert_close(b.X, c.X.detach(), rtol=2e-5, what="X"); assert_close(b.E, c.E.detach(), rtol=2e-5, what="E")
-    assert_close(b.y, c.y.detach(), rtol=2e-5, what="y")
+    assert_close(b2.X, c2.X.detach(), what="X, n = 70"); assert_close(b2.E, c2.E.detach(), what="E, n = 70")
+    assert_close(b.X, c.X.detach(), what="X"); assert_close(b.E, c.E.detach(), what="E")
+    assert_close(b.y, c.y.detach(), what="y")
 
 
 def test_sample_batch_full_width_packed_path(monkeypatch):
@@ -1131,7 +1132,7 @@ def test_sample_batch_full_width_packed_path(monkeypatch):
     pair = (mask.unsqueeze(1) & mask.unsqueeze(2))
     for k, valid, expo in ((0, mask, eX.reshape(bs, n, 5)), (1, pair, eE.reshape(bs, n, n, 5))):
         # probabilities of valid rows: the sparse order pools padding pairs analytically (same mathematics, other rounding)
-        assert_close(a["prob"][k][valid], b["prob"][k][valid], rtol=5e-5, what="step probabilities, packed vs dense")
+        assert_close(a["prob"][k][valid], b["prob"][k][valid], what="step probabilities, packed vs dense")
         assert _flip_ok(b["prob"][k][valid], a["cls"][k][valid], b["cls"][k][valid], expo[valid]), "a sample differs away from a tie"
     for kw in (dict(use_graph=True), dict(balance=True, use_graph=True), dict(size_buckets=2)):
         for grp, n in zip(run(**kw), sizes.tolist()):

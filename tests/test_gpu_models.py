@@ -65,10 +65,9 @@ def test_blocks_and_heads_golden(name):
     sum((o * g[f"{name}_cot{i}"].cuda()).sum() for i, o in enumerate(outs)).backward()
     params = dict(mod.named_parameters())
     for k, v in g["pg_" + name].items():
-        # reductions over <= 64 terms per element: 2e-5 covers the different summation order of the MFMA tiles
-        assert_close(params[k].grad, v, rtol=2e-5, atol=1e-6 if _is_null_grad(k) else None, what=f"{name} grad {k}")
+        assert_close(params[k].grad, v, atol=1e-6 if _is_null_grad(k) else None, what=f"{name} grad {k}")
     for i, t in enumerate(leaves):
-        assert_close(t.grad, g[f"{name}_din{i}"], rtol=2e-5, what=f"{name} input grad {i}")
+        assert_close(t.grad, g[f"{name}_din{i}"], what=f"{name} input grad {i}")
 
 
 # ------------------------------------------------------------------------------------------------ model variants
@@ -126,8 +125,7 @@ def test_model_variants_common_step_golden(name):
     params = dict(model.named_parameters())
     assert set(g[name + "_grad"]) == {k for k, p in params.items() if p.grad is not None}
     for k, v in g[name + "_grad"].items():
-        # whole-network gradients: chains of <= 12 products with reductions of <= 64 terms; 3e-5 of the tensor's scale
-        assert_close(params[k].grad, v, rtol=3e-5, atol=1e-6 if _is_null_grad(k) else None, what="grad " + k)
+        assert_close(params[k].grad, v, atol=1e-6 if _is_null_grad(k) else None, what="grad " + k)
     # the Lightning-style steps return the same loss and log it
     model.zero_grad()
     batch["y"] = {k: (v.bool() if k.endswith("_mask") else v).cuda() for k, v in g["y"].items()}
@@ -209,24 +207,24 @@ def test_validation_step_elbo_golden():
     assert torch.equal(gd.X_t.cpu(), g["X_t"]) and torch.equal(gd.E_t.cpu(), g["E_t"])
     assert_close(gd.X_extra, g["X_extra"], what="X_extra (reference gauge)"); assert_close(gd.y_extra, g["y_extra"], what="y_extra")
     out = pred.graph_reconstruction
-    # two layers deep, every output a chain of ~20 products over reductions of <= 81 pairs: 2e-5 of the logit scale
-    assert_close(out.X, g["pred_X"], rtol=2e-5, what="logits X"); assert_close(out.E, g["pred_E"], rtol=2e-5, what="logits E")
-    assert_close(seen["X"], g["probX0"], rtol=2e-5, what="probX0"); assert_close(seen["E"], g["probE0"], rtol=2e-5, what="probE0")
+    assert_close(out.X, g["pred_X"], what="logits X"); assert_close(out.E, g["pred_E"], what="logits E")
+    assert_close(seen["X"], g["probX0"], what="probX0"); assert_close(seen["E"], g["probE0"], what="probE0")
     parts = loss.components
     # KL(q(z_T | x) || limit) is ~alpha_bar_T^2 ~ 1e-7 at T = 500: what both sides hold is the rounding of ~400 differences
     # of O(1) log-probabilities, compared absolutely
     assert_close(parts["kl prior"], g["kl_prior"], atol=2e-6, what="KL prior"); assert_close(parts["log_pn"], g["log_pn"], what="log p(N)")
-    # T * KL and the t = 0 term sum ~400 log-probabilities each: 2e-5 of their value
-    assert_close(parts["Estimator loss terms"], g["Lt"], rtol=2e-5, what="T * KL"); assert_close(parts["loss_term_0"], g["loss_term_0"], rtol=2e-5, what="t = 0 term")
-    assert_close(loss.reconstruction, g["nll"], rtol=2e-5, what="NLL")
+    assert_close(parts["Estimator loss terms"], g["Lt"], what="T * KL"); assert_close(parts["loss_term_0"], g["loss_term_0"], what="t = 0 term")
+    assert_close(loss.reconstruction, g["nll"], what="NLL")
     assert_close(loss.complexity, g["loss_complexity"], what="KL"); assert_close(loss.contrastive, g["loss_contrastive"], what="contrastive")
-    assert_close(loss.compute_loss(model.weights), g["loss_total"], rtol=2e-5, what="total")
+    assert_close(loss.compute_loss(model.weights), g["loss_total"], what="total")
     assert not model.replay["expX"] and not model.replay["lcc_noise"], "the step must have consumed both sets of draws"
     # epoch end: the five running ELBO metrics are logged and reset (sampling skipped: no buffered embeddings here)
     model.on_validation_epoch_end()
     for key, ref in (("val/epoch_NLL", "epoch_NLL"), ("val/X_kl", "epoch_X_kl"), ("val/E_kl", "epoch_E_kl"), ("val/X_logp", "epoch_X_logp"),
                      ("val/E_logp", "epoch_E_logp")):
-        assert_close(torch.as_tensor(model.logged[key]), g[ref], rtol=2e-5, what=key)
+        # the two KL trackers are multiplied by T = 500 after summing ~400 (X: 36) clamped log-ratios of fp32 softmax
+        # outputs whose own relative rounding is ~1e-7 per term: measured 1.2e-5 (X), 1.4e-6 (E); bound 2e-5
+        assert_close(torch.as_tensor(model.logged[key]), g[ref], rtol=2e-5 if key.endswith("_kl") else 1e-5, what=key)
     assert model.val_nll.count == 0 and model.val_X_kl.count == 0
 
 
@@ -322,3 +320,28 @@ def test_epoch_end_hooks_sample_log_and_reset():
     model.training_step(batch, 0)
     model.on_train_epoch_end()
     assert "train/atom_CCE" in model.logged and "train/bond_AromaticCE" in model.logged and model.train_mol.atom_sum is None
+
+
+# ------------------------------------------------------------------------------------------------ conditioned generation
+def test_conditional_generator_latent_optimisation_golden():
+    """The batched latent optimisation against the reference's one-latent-at-a-time Adam loop run on the reference's own
+    fusion / DTI-head modules (validating/conditioning.py:333-391): best latents and best probabilities per
+    (target, sample)."""
+    from mbvae_amd.conditioning import ConditionalDrugGenerator
+    from tests.test_gpu_kernels import _tiny_full_model
+    g = load_golden("conditioning")
+    cs = load_golden("common_step")
+    model = _tiny_full_model("train", cs, cs["sd"])
+    missing, unexpected = model.load_state_dict({k: v.cuda() for k, v in g["sd"].items()}, strict=False)
+    assert not unexpected
+    model.eval()
+    gen = ConditionalDrugGenerator(model, max_batch_size=8)
+    k, steps, lr = int(g["per_target"]), int(g["steps"]), float(g["lr"])
+    flags = torch.zeros(g["latents"].shape[0])
+    best, meta = gen.optimize_latents_for_interaction(g["latents"].cuda(), flags, g["targets"].cuda(), n_samples_per_target=k,
+                                                      n_optimization_steps=steps, learning_rate=lr)
+    assert_close(meta[:, 3], g["scores"], what="best probabilities")
+    # 12 Adam steps: the update direction g / (sqrt(v) + eps) amplifies the gradient's rounding where |g| is small;
+    # the latents themselves (O(1) values moved by <= 12 * lr) agree to 1e-5 of their scale
+    assert_close(best, g["best"], what="optimised latents")
+    assert meta[:, 0].tolist() == [0, 0, 0, 1, 1, 1] and meta[:, 1].tolist() == [0, 1, 2, 0, 1, 2]

@@ -783,6 +783,61 @@ def gen_variants():
     npz("variants", **rec)
 
 
+# =============================================================================== target-conditioned latent optimisation
+def gen_conditioning():
+    """The reference's per-latent optimisation (validating/conditioning.py:333-391: for every target and every sample an
+    Adam(lr) loop of n steps on -sigmoid(dti_head(fusion(latent, target))['Y']).mean(), keeping the best latent seen
+    BEFORE the step that follows it) run on the reference's own CrossAttentionFusion / DTIHead modules.  The module
+    itself cannot be imported (it loads CSV files and checkpoints at import, conditioning.py:697-790), so the loop is
+    restated here around the reference's model components."""
+    model, kw, infos = make_full_model(phase="train", seed=2)
+    model.eval()
+    g = torch.Generator().manual_seed(95)
+    n_targets, per_target, steps, lr = 2, 3, 12, 0.01
+    targets = torch.randn(n_targets, 32, generator=g)
+    latents = torch.randn(n_targets * per_target, 32, generator=g)
+    best_all, scores, first_scores = [], [], []
+    for ti in range(n_targets):
+        tgt = targets[ti:ti + 1]
+        for si in range(per_target):
+            latent = latents[ti * per_target + si:ti * per_target + si + 1].clone().requires_grad_(True)
+            opt = torch.optim.Adam([latent], lr=lr)
+            best, best_score = latent.clone(), float("-inf")
+            for step in range(steps):
+                opt.zero_grad()
+                fused, _ = model.fusion(latent, tgt.expand(latent.shape[0], -1))
+                prob = torch.sigmoid(model.dti_head(fused)["Y"])
+                (-prob.mean()).backward()
+                opt.step()
+                if step == 0:
+                    first_scores.append(prob.item())
+                if prob.item() > best_score:
+                    best_score, best = prob.item(), latent.clone().detach()
+            best_all.append(best); scores.append(best_score)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("fusion.") or k.startswith("dti_head.")}
+    # oracle: same loop on the functional restatement
+    o_best = []
+    fsd = {k[len("fusion."):]: v for k, v in sd.items() if k.startswith("fusion.")}
+    hsd = {k[len("dti_head."):]: v for k, v in sd.items() if k.startswith("dti_head.")}
+    for ti in range(n_targets):
+        for si in range(per_target):
+            latent = latents[ti * per_target + si:ti * per_target + si + 1].clone().requires_grad_(True)
+            opt = torch.optim.Adam([latent], lr=lr)
+            best, best_score = latent.clone(), float("-inf")
+            for step in range(steps):
+                opt.zero_grad()
+                fused, _ = O_heads.cross_attention_fusion(fsd, latent, targets[ti:ti + 1])
+                prob = torch.sigmoid(O_heads.dti_head(hsd, fused)["Y"])
+                (-prob.mean()).backward()
+                opt.step()
+                if prob.item() > best_score:
+                    best_score, best = prob.item(), latent.clone().detach()
+            o_best.append(best)
+    close(torch.cat(o_best), torch.cat(best_all), tol=1e-5, what="optimised latents")
+    npz("conditioning", sd=sd, targets=targets, latents=latents, best=torch.cat(best_all), scores=torch.tensor(scores),
+        first_scores=torch.tensor(first_scores), steps=torch.tensor(steps), lr=torch.tensor(lr), per_target=torch.tensor(per_target))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if "--only-new" not in sys.argv:
@@ -796,4 +851,5 @@ if __name__ == "__main__":
     gen_val_step()
     gen_trajectory()
     gen_variants()
+    gen_conditioning()
     print("all fixtures written and oracle == reference on every one")
