@@ -548,7 +548,9 @@ def test_full_model_common_step_golden():
     for k, v in g["gradnorm"].items():
         got = dict(model.named_parameters())[k].grad
         assert got is not None, k
-        assert abs(float(got.norm()) - float(v)) <= 1e-5 * float(v), f"grad norm {k}: {float(got.norm())} vs {float(v)}"
+        # (the attention-logit bias gradients are zero in exact arithmetic -- softmax shift invariance -- and hold rounding noise)
+        bound = 1e-6 if k.endswith("to_attn_logits.bias") else 1e-5 * float(v)
+        assert abs(float(got.norm()) - float(v)) <= bound, f"grad norm {k}: {float(got.norm())} vs {float(v)}"
 
 
 def test_full_model_sampling_and_val_step_run():
