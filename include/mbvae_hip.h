@@ -190,6 +190,13 @@ int mbvae_sym_mask(const float* x, const float* s, int64_t lds, const uint8_t* m
 int64_t mbvae_masked_ce_workspace(void);
 int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, int64_t rows, int64_t C,
                         void* workspace, int64_t ws_bytes, mbvae_stream_t stream);
+/* mbvae_masked_ce_fwd for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): no workspace argument, no allocation of any kind inside.  No counterpart in the reference.
+ * The partial sums live in a 72 KB array inside the library (one copy per GPU, held until the process ends).  Same
+ * result, bit for bit, as mbvae_masked_ce_fwd.  rows <= 2^27, else -2 (and a message on stderr).  Calls that overlap
+ * on one GPU share the array and race: issue them on one stream, or serialise them. */
+int mbvae_masked_ce_fwd_static(const float* logits, const float* target, float* out, int64_t rows, int64_t C,
+                               mbvae_stream_t stream);
 int mbvae_masked_ce_bwd(const float* logits, const float* target, const float* coef, float* dlogits, int64_t rows,
                         int64_t C, mbvae_stream_t stream);
 

@@ -134,6 +134,33 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
   }
 }
 
+// ---- scratch of the allocation-free entry point ------------------------------------------------------------
+// One partial-sum row per workgroup of ce_fwd_kernel (at most 1024 of them): 72 KB that every GPU the library runs on
+// holds until the process ends.  The array's NAME is only a host-side handle: kernels get the device address that
+// hipGetSymbolAddress returns for the current device (each GPU has its own copy at its own address).
+#define CE_STATIC_MAX_BLOCKS 1024
+#define CE_STATIC_MAX_ROWS ((int64_t)1 << 27)
+static __device__ __align__(256) float ce_static_scratch[CE_STATIC_MAX_BLOCKS * (2 + CE_MAX_C)];
+
+// Device address of ce_static_scratch on the current device, looked up once per device; nullptr on failure.
+static float* ce_static_scratch_ptr() {
+  static std::atomic<float*> table[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  float* p = table[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(ce_static_scratch));
+    if (e != hipSuccess || sym == nullptr) {
+      fprintf(stderr, "libmbvae_hip: hipGetSymbolAddress(ce_static_scratch) failed on device %d: %s\n", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    p = (float*)sym;
+    table[dev].store(p, std::memory_order_release);     // (racing threads look up the same address)
+  }
+  return p;
+}
+
 extern "C" {
 
 int64_t mbvae_masked_ce_workspace() { return (int64_t)sizeof(float) * 1024 * (2 + CE_MAX_C); }
@@ -148,6 +175,28 @@ int mbvae_masked_ce_fwd(const float* logits, const float* target, float* out, in
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 1024);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, target, (float*)workspace, rows, (int)C);
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, out, blocks);
+  return mbvae_launch_status();
+}
+
+// mbvae_masked_ce_fwd without a workspace argument and without any allocation: the per-workgroup partial sums go to a
+// file-scope device array (72 KB per GPU).  Same kernels, same launch shape, hence the same bits as mbvae_masked_ce_fwd.
+// Nothing in the array has to start at zero: the first kernel overwrites every row the second one reads.  All calls
+// on one GPU share the array, so calls that overlap on one GPU (different streams or threads) race; serialise them.
+int mbvae_masked_ce_fwd_static(const float* logits, const float* target, float* out, int64_t rows, int64_t C,
+                               hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!logits || !target || !out || rows <= 0) return MBVAE_EINVAL;
+  if (C <= 0 || C > CE_MAX_C) return MBVAE_EUNSUPPORTED;
+  if (rows > CE_STATIC_MAX_ROWS) {
+    fprintf(stderr, "libmbvae_hip: mbvae_masked_ce_fwd_static takes at most %lld rows (got %lld); use mbvae_masked_ce_fwd\n",
+            (long long)CE_STATIC_MAX_ROWS, (long long)rows);
+    return MBVAE_EUNSUPPORTED;
+  }
+  float* scratch = ce_static_scratch_ptr();
+  if (!scratch) return MBVAE_ELAUNCH;
+  const int blocks = (int)std::min<int64_t>((rows + 255) / 256, CE_STATIC_MAX_BLOCKS);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, target, scratch, rows, (int)C);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)scratch, out, blocks);
   return mbvae_launch_status();
 }
 

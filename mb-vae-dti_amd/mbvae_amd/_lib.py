@@ -36,6 +36,7 @@ SIGNATURES = {
     "mbvae_sym_mask": [_P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
     "mbvae_masked_ce_workspace": [],
     "mbvae_masked_ce_fwd": [_P, _P, _P, _L, _L, _P, _L, _P],
+    "mbvae_masked_ce_fwd_static": [_P, _P, _P, _L, _L, _P],
     "mbvae_masked_ce_bwd": [_P, _P, _P, _P, _L, _L, _P],
     "mbvae_kl_workspace": [],
     "mbvae_kl_reparam_fwd": [_P, _P, _P, _P, _P, _L, _P, _L, _P],
