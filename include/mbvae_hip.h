@@ -29,8 +29,9 @@ typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
 /* ---- tuning switches ------------------------------------------------------------------------------------
  * No counterpart in the reference.  Process-wide switches that choose between equivalent HIP routes (kernel A/B
  * timing, parity tests of the fallback kernels; never a CPU path).  Names: "NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64",
- * "NO_TSWGRAD", "NO_TSWGRAD2", "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED" (0 / 1) and
- * "GEMM_TILE" (-1 automatic, 0 = 64x64, 1 = 128x64, 2 = 128x128).  Each starts from the environment variable
+ * "NO_TSWGRAD", "NO_TSWGRAD2", "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED", "NO_EA_PREFETCH" (0 / 1),
+ * "EA_KEYS" (8, else 16 keys per wave in the attention backward) and "GEMM_TILE" (-1 automatic, 0 = 64x64,
+ * 1 = 128x64, 2 = 128x128).  Each starts from the environment variable
  * MBVAE_<NAME>, read once.  mbvae_set_option: 0, or -1 for an unknown name.  mbvae_get_option: the value (-1 for an
  * unknown name).  A change takes effect at the next entry-point call. */
 int mbvae_set_option(const char* name, int value);
@@ -72,15 +73,20 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
  * q|k|v resp. e_mul|e_add projection output); ye_add,ye_mul [bs,dx]; mask [bs,n].  Dense outputs: P [bs,n,n,dx]
  * is the input of e_out, wV [bs,n,dx], lse [bs,n,dx] (log-sum-exp per query row and channel, kept for backward).
  * Backward writes dE1,dE2 / dQ,dK,dV with the same strides as their forward counterparts.
- * dx, ldq, lde % 4 == 0. */
+ * Forward: dx, ldq, lde % 4 == 0. */
 int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
                         int64_t lde, const float* ye_add, const float* ye_mul, const uint8_t* mask, float* P,
                         float* wV, float* lse, int64_t bs, int64_t n, int64_t dx, float scale, mbvae_stream_t stream);
+/* Backward workspace: the per-key-group partial sums of dQ / dye_add / dye_mul (16 keys per group), added in a fixed
+ * order by a second kernel, so the gradients are bitwise reproducible.  mbvae_edge_attn_bwd_workspace bytes run the
+ * whole batch in one launch; with less the call walks over the batch in chunks of graphs (-1 if not even one graph
+ * fits; nothing is needed when n <= 16). */
+int64_t mbvae_edge_attn_bwd_workspace(int64_t bs, int64_t n, int64_t dx);
 int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
                         int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
                         const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK, float* dV,
                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx, float scale,
-                        mbvae_stream_t stream);
+                        void* workspace, int64_t ws_bytes, mbvae_stream_t stream);
 
 /* ---- e_mul|e_add projection + edge attention in one forward kernel --------------------------------------
  * Replaces graph_transformer.py:206-249 together with the e_mul / e_add Linear layers of :196-204 that feed it:

@@ -34,13 +34,15 @@ static inline int mbvae_launch_status() {
 enum MbvaeOption {
   MBVAE_OPT_NO_TSGEMM, MBVAE_OPT_NO_TSGEMM2, MBVAE_OPT_TSGEMM_N64, MBVAE_OPT_NO_TSWGRAD, MBVAE_OPT_NO_TSWGRAD2,
   MBVAE_OPT_NO_EDGE_FUSED, MBVAE_OPT_NO_EDGE_FFN, MBVAE_OPT_NO_SMALLM, MBVAE_OPT_NO_EDGE_TRAIN_FUSED,
+  MBVAE_OPT_EA_KEYS,       // keys per wave of the edge-attention backward: 8, anything else = 16
+  MBVAE_OPT_NO_EA_PREFETCH,   // edge-attention backward: do NOT request the next query row's operands a row ahead
   MBVAE_OPT_GEMM_TILE,     // -1: automatic; 0 = 64x64, 1 = 128x64, 2 = 128x128
   MBVAE_OPT_COUNT
 };
 inline const char* const* mbvae_option_names() {
   static const char* const names[MBVAE_OPT_COUNT] = {"NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64", "NO_TSWGRAD", "NO_TSWGRAD2",
                                                      "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
-                                                     "GEMM_TILE"};
+                                                     "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE"};
   return names;
 }
 struct MbvaeOptions {
@@ -51,7 +53,7 @@ struct MbvaeOptions {
       snprintf(name, sizeof(name), "MBVAE_%s", mbvae_option_names()[i]);
       const char* e = getenv(name);
       int val = i == MBVAE_OPT_GEMM_TILE ? -1 : 0;
-      if (e) val = i == MBVAE_OPT_GEMM_TILE ? (*e ? atoi(e) : -1) : 1;
+      if (e) val = (i == MBVAE_OPT_GEMM_TILE || i == MBVAE_OPT_EA_KEYS) ? (*e ? atoi(e) : (i == MBVAE_OPT_GEMM_TILE ? -1 : 0)) : 1;
       v[i].store(val, std::memory_order_relaxed);
     }
   }

@@ -12,11 +12,9 @@
 //
 // Forward: one wave per query row (b,i), online (running max / sum) softmax over j; also stores
 // lse = max + log(sum) per (b,i,c) so that backward can rebuild A without a second reduction.
-// Backward: every (i,j,c) element is independent once lse and wV are known.  One 512-thread
-// workgroup per (graph, 16 keys): a wave owns two keys (dK/dV accumulate in registers over the
-// i loop), the per-query sums dQ[i] are combined across the 8 waves with LDS float adds and across
-// the key groups with global float adds.
+// Backward: every (i,j,c) element is independent once lse and wV are known; see edge_attn_bwd_kernel.
 #include "common.h"
+#include <algorithm>
 
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -109,136 +107,162 @@ __global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
   st4(lse + (node + i) * dx + c, s);
 }
 
-// grid: (ceil(dx/256), ceil(n/KPB), bs), block 64*NW: wave w owns keys j = KPB*blockIdx.y + w + NW*jj (jj < 2, KPB =
-// 2*NW keys per block), lane = 4 channels.  dQ/dye_* are accumulated with global float adds across the key groups
-// (zeroed by the host).  Block shape (measured at bs=256, n=64, dx=256): 8 waves x 32 query rows per LDS pass keeps
-// three independent workgroups on a CU and runs 14 % faster than one 16-wave workgroup with 64 rows; requesting the
-// next query row's streams ahead of the arithmetic (two rows in flight per wave) did not help at either shape.
-#define EA_JPW 2
-template <int NW, int ROWS>
-__global__ __launch_bounds__(64 * NW) void edge_attn_bwd_kernel(
+// Backward.  One wave owns (graph b, a group of KPW consecutive keys, 64 consecutive channels): lane = ONE channel.
+// The wave walks over the query rows i; for every row it requests the 3 * KPW stream words (E1, E2, dP of its keys:
+// each a 256-byte row segment per instruction, touched once, non-temporal) plus the row's q / lse / wV / dwV, then
+// works through its keys.  Everything that is summed lives in the lane's own registers:
+//   dK[j], dV[j]  (sum over i)            -> stored once at the end, each key has exactly one owner per channel
+//   dQ[i]         (sum over the KPW keys) -> one partial per key group, plain store
+//   dye_add/mul   (sum over i and keys)   -> one partial per key group
+// and a second tiny kernel adds the key groups' partials in index order.  No LDS, no barrier, no atomic: the result
+// is bitwise reproducible from run to run.  The four waves of a workgroup are the four channel quarters of one
+// (graph, key group), so together they read whole 1 KiB rows.
+template <int KPW, bool PREFETCH>
+__global__ __launch_bounds__(256) void edge_attn_bwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ E1, const float* __restrict__ E2,
     const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
     const float* __restrict__ wV, const float* __restrict__ lse,
     const float* __restrict__ dP, const float* __restrict__ dwV,
-    float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dQ, float* __restrict__ dK,
-    float* __restrict__ dV, float* __restrict__ dye_add, float* __restrict__ dye_mul, int n, int dx, float scale,
-    int ldq, int lde) {
-  constexpr int KPB = NW * EA_JPW, NT = 64 * NW;
-  __shared__ float dq_acc[ROWS * 256];
-  __shared__ float dya_acc[256], dym_acc[256];
-  // V rows of this block's keys: re-read for every query row; from global memory they get evicted from L1/L2 by
-  // the edge streams in between and come back from HBM (measured: +1 GB of fetches per launch)
-  __shared__ __align__(16) float v_rows[KPB * 256];
+    float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dK, float* __restrict__ dV,
+    float* __restrict__ dq_out, int64_t dq_ld, int64_t dq_group_stride,      // dQ itself (one key group) or the partials
+    float* __restrict__ dye_out, int64_t dye_group_stride,                   // [group][b][2][dx] (or dye_add|dye_mul ...)
+    float* __restrict__ dye_add, float* __restrict__ dye_mul,                // ... written directly when there is one group
+    int b0, int nb, int n, int dx, float scale, int ldq, int lde, int n_kg, int n_cq) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addressing on the scalar unit
-  const int b = blockIdx.z;
-  const int c = blockIdx.x * 256 + lane * 4;
-  const int cbase = blockIdx.x * 256;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  const int cq = (int)(w % n_cq);
+  const int64_t kgb = w / n_cq;
+  const int kg = (int)(kgb % n_kg);
+  const int bl = (int)(kgb / n_kg);                 // graph within this launch's chunk
+  if (bl >= nb) return;
+  const int b = b0 + bl;
+  const int c = cq * 64 + lane;
   const bool active = c < dx;
-  const int cc = active ? c : 0;                   // inactive lanes load from channel 0 and store nothing
+  const int cc = active ? c : 0;                   // inactive lanes read channel 0 and store nothing
   const int64_t node = (int64_t)b * n;
-  if (threadIdx.x < 256) { dya_acc[threadIdx.x] = 0.f; dym_acc[threadIdx.x] = 0.f; }
+  const int j0 = kg * KPW;
 
-  float4 ks[EA_JPW], dk[EA_JPW], dv[EA_JPW];
-  bool ok[EA_JPW], inr[EA_JPW];
-  int jc[EA_JPW];
-  float4 ym = make_float4(1.f, 1.f, 1.f, 1.f);
-  float4 dya = make_float4(0.f, 0.f, 0.f, 0.f), dym = dya;
+  float ks[KPW], vj[KPW], dk[KPW], dv[KPW];
+  unsigned okbits = 0u;                            // bit t: key j0 + t exists and is not masked (wave-uniform)
 #pragma unroll
-  for (int jj = 0; jj < EA_JPW; ++jj) {
-    const int j = blockIdx.y * KPB + wave + NW * jj;
-    inr[jj] = j < n;
-    jc[jj] = min(j, n - 1);
-    dk[jj] = make_float4(0.f, 0.f, 0.f, 0.f); dv[jj] = dk[jj];
-    const float4 k = ld4(K + (node + jc[jj]) * ldq + cc);
-    st4(&v_rows[(wave + NW * jj) * 256 + lane * 4], ld4(V + (node + jc[jj]) * ldq + cc));   // read back by this lane only
-    F4_OP(ks[jj], f4get(k, _q) * scale);
-    ok[jj] = inr[jj] && mask[node + jc[jj]] != 0;
+  for (int t = 0; t < KPW; ++t) {
+    const int j = min(j0 + t, n - 1);
+    ks[t] = K[(node + j) * ldq + cc] * scale;
+    vj[t] = V[(node + j) * ldq + cc];
+    if ((j0 + t < n) && mask[node + j] != 0) okbits |= 1u << t;
+    dk[t] = 0.f; dv[t] = 0.f;
   }
-  {
-    const float4 t = ld4(ye_mul + (int64_t)b * dx + cc);
-    ym.x += t.x; ym.y += t.y; ym.z += t.z; ym.w += t.w;
-  }
+  okbits = __builtin_amdgcn_readfirstlane(okbits);
+  const float ym = ye_mul[(int64_t)b * dx + cc] + 1.f;
+  float dya = 0.f, dym = 0.f;
+  const int nk = min(KPW, n - j0);                 // keys of this group that exist (wave-uniform)
 
-  float4 e1[1][EA_JPW], e2[1][EA_JPW], dp[1][EA_JPW], q4[1], ls4[1], wv4[1], dwv4[1];
-#define EA_LOAD(i_, S)                                                                     \
-  {                                                                                        \
-    const int64_t nrow = node + min((i_), n - 1);                                          \
-    q4[S] = ld4(Q + nrow * ldq + cc);                                                      \
-    ls4[S] = ld4(lse + nrow * dx + cc);                                                    \
-    wv4[S] = ld4(wV + nrow * dx + cc);                                                     \
-    dwv4[S] = ld4(dwV + nrow * dx + cc);                                                   \
-    _Pragma("unroll") for (int jj = 0; jj < EA_JPW; ++jj) {                                \
-      e1[S][jj] = ld4s(E1 + (nrow * n + jc[jj]) * (int64_t)lde + cc);                      \
-      e2[S][jj] = ld4s(E2 + (nrow * n + jc[jj]) * (int64_t)lde + cc);                      \
-      dp[S][jj] = ld4s(dP + (nrow * n + jc[jj]) * (int64_t)dx + cc);                       \
-    }                                                                                      \
-    asm volatile("" : : : "memory");         /* issue the loads here */                    \
-  }
-#define EA_ROW(i_, ii_, S)                                                                 \
-  {                                                                                        \
-    const float4 q = q4[S], ls = ls4[S], wv = wv4[S], dwv = dwv4[S];                       \
-    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
-    const int64_t nrow = node + (i_);                                                      \
-    _Pragma("unroll") for (int jj = 0; jj < EA_JPW; ++jj) {                                \
-      const float4 x1 = e1[S][jj], x2 = e2[S][jj], dpp = dp[S][jj];                        \
-      const float4 vj = ld4(&v_rows[(wave + NW * jj) * 256 + lane * 4]);                   \
-      float4 qk; F4_OP(qk, f4get(q, _q) * f4get(ks[jj], _q));                              \
-      float4 y; F4_OP(y, f4get(qk, _q) * (f4get(x1, _q) + 1.f) + f4get(x2, _q));           \
-      float4 a; F4_OP(a, ok[jj] ? __expf(f4get(y, _q) - f4get(ls, _q)) : 0.f);             \
-      float4 dy; F4_OP(dy, f4get(dpp, _q) * f4get(ym, _q) +                                \
-                             f4get(a, _q) * f4get(dwv, _q) * (f4get(vj, _q) - f4get(wv, _q))); \
-      if (inr[jj] && active) {                                                             \
-        float4 t; F4_OP(t, f4get(dy, _q) * f4get(qk, _q));                                 \
-        st4s(dE1 + (nrow * n + jc[jj]) * (int64_t)lde + c, t);                             \
-        st4s(dE2 + (nrow * n + jc[jj]) * (int64_t)lde + c, dy);                            \
-        float4 g; F4_OP(g, f4get(dy, _q) * (f4get(x1, _q) + 1.f));                         \
-        F4_OP(dq, f4get(dq, _q) + f4get(g, _q) * f4get(ks[jj], _q));                       \
-        F4_OP(dk[jj], f4get(dk[jj], _q) + f4get(g, _q) * f4get(q, _q) * scale);            \
-        F4_OP(dv[jj], f4get(dv[jj], _q) + f4get(a, _q) * f4get(dwv, _q));                  \
-        F4_OP(dya, f4get(dya, _q) + f4get(dpp, _q));                                       \
-        F4_OP(dym, f4get(dym, _q) + f4get(dpp, _q) * f4get(y, _q));                        \
-      }                                                                                    \
-    }                                                                                      \
-    float* slot = &dq_acc[(ii_) * 256 + lane * 4];                                         \
-    atomicAdd(slot + 0, dq.x); atomicAdd(slot + 1, dq.y); atomicAdd(slot + 2, dq.z); atomicAdd(slot + 3, dq.w); \
-  }
-
-  for (int i0 = 0; i0 < n; i0 += ROWS) {
-    const int rows = min(ROWS, n - i0);
-    for (int t = threadIdx.x; t < rows * 256; t += NT) dq_acc[t] = 0.f;
-    __syncthreads();
-#pragma unroll 1
-    for (int ii = 0; ii < rows; ++ii) {
-      EA_LOAD(i0 + ii, 0)
-      EA_ROW(i0 + ii, ii, 0)
+  // Stream addressing through buffer descriptors: the row base sits in scalar registers, the key offset is a scalar
+  // immediate-like operand and only the lane's channel offset is a vector register.  (Flat 64-bit addresses for the
+  // 48 loads and 32 stores of a row would by themselves fill the register file.)
+  const int voff = cc * 4;
+  const unsigned e_key = (unsigned)lde * 4u, p_key = (unsigned)dx * 4u;        // bytes from one key's row to the next
+  struct RowRegs { float x1[KPW], x2[KPW], dpv[KPW], q, ls, wv, dwv; };
+  // requests one query row's operands (nothing is waited for here)
+  auto load_row = [&](int i, RowRegs& r) {
+    const int64_t nrow = node + min(i, n - 1);
+    const int64_t eoff = (nrow * n + j0) * (int64_t)lde, poff = (nrow * n + j0) * (int64_t)dx;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(E1 + eoff), 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(E2 + eoff), 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dP + poff), 0, nk * (int)p_key, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < KPW; ++t) {
+      const int tt = min(t, nk - 1);               // clamped: the loads stay unconditional
+      r.x1[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, voff, tt * (int)e_key, 2));
+      r.x2[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, voff, tt * (int)e_key, 2));
+      r.dpv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, voff, tt * (int)p_key, 2));
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < rows * 256; t += NT) {
-      const int ii = t >> 8, ch = t & 255;
-      if (cbase + ch < dx) atomicAdd(&dQ[(node + i0 + ii) * ldq + cbase + ch], dq_acc[t]);
+    r.q = Q[nrow * ldq + cc]; r.ls = lse[nrow * dx + cc]; r.wv = wV[nrow * dx + cc]; r.dwv = dwV[nrow * dx + cc];
+    asm volatile("" : : : "memory");               // the loads are issued HERE
+  };
+  auto compute_row = [&](int i, const RowRegs& r) {
+    const int64_t nrow = node + i;
+    const int64_t eoff = (nrow * n + j0) * (int64_t)lde;
+    const __amdgpu_buffer_rsrc_t w1 = __builtin_amdgcn_make_buffer_rsrc(dE1 + eoff, 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2 = __builtin_amdgcn_make_buffer_rsrc(dE2 + eoff, 0, nk * (int)e_key, 0x00020000);
+    float dq = 0.f;
+#pragma unroll
+    for (int t = 0; t < KPW; ++t) {
+      if (t < nk) {
+        const float qk = r.q * ks[t];
+        const float y = qk * (r.x1[t] + 1.f) + r.x2[t];
+        const float a = ((okbits >> t) & 1u) ? __expf(y - r.ls) : 0.f;
+        const float dy = r.dpv[t] * ym + a * r.dwv * (vj[t] - r.wv);
+        if (active) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy * qk), w1, voff, t * (int)e_key, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy), w2, voff, t * (int)e_key, 2);
+        }
+        const float g = dy * (r.x1[t] + 1.f);
+        dq += g * ks[t];
+        dk[t] += g * r.q * scale;
+        dv[t] += a * r.dwv;
+        dya += r.dpv[t];
+        dym += r.dpv[t] * y;
+      }
     }
-    __syncthreads();
+    if (active) dq_out[(int64_t)kg * dq_group_stride + ((int64_t)bl * n + i) * dq_ld + c] = dq;
+#ifdef EA_ROW_BARRIER
+    asm volatile("s_barrier" : : : "memory");
+#endif
+  };
+  if (PREFETCH) {
+    // the next row's operands are in flight underneath this row's arithmetic (two register sets, loop unrolled by 2)
+    RowRegs ra, rb;
+    load_row(0, ra);
+    for (int i = 0; i < n; i += 2) {
+      load_row(i + 1, rb);
+      compute_row(i, ra);
+      load_row(i + 2, ra);
+      if (i + 1 < n) compute_row(i + 1, rb);
+    }
+  } else {
+    RowRegs ra;
+    for (int i = 0; i < n; ++i) {
+      load_row(i, ra);
+      compute_row(i, ra);
+    }
   }
-#undef EA_LOAD
-#undef EA_ROW
   if (active) {
 #pragma unroll
-    for (int jj = 0; jj < EA_JPW; ++jj) {
-      const int j = blockIdx.y * KPB + wave + NW * jj;
-      if (j < n) { st4(dK + (node + j) * ldq + c, dk[jj]); st4(dV + (node + j) * ldq + c, dv[jj]); }
+    for (int t = 0; t < KPW; ++t)
+      if (t < nk) { dK[(node + j0 + t) * ldq + c] = dk[t]; dV[(node + j0 + t) * ldq + c] = dv[t]; }
+    if (n_kg == 1) {
+      dye_add[(int64_t)b * dx + c] = dya; dye_mul[(int64_t)b * dx + c] = dym;
+    } else {
+      float* o = dye_out + (int64_t)kg * dye_group_stride + (int64_t)bl * 2 * dx;
+      o[c] = dya; o[dx + c] = dym;
     }
-    atomicAdd(&dya_acc[lane * 4 + 0], dya.x); atomicAdd(&dya_acc[lane * 4 + 1], dya.y);
-    atomicAdd(&dya_acc[lane * 4 + 2], dya.z); atomicAdd(&dya_acc[lane * 4 + 3], dya.w);
-    atomicAdd(&dym_acc[lane * 4 + 0], dym.x); atomicAdd(&dym_acc[lane * 4 + 1], dym.y);
-    atomicAdd(&dym_acc[lane * 4 + 2], dym.z); atomicAdd(&dym_acc[lane * 4 + 3], dym.w);
   }
-  __syncthreads();
-  if (threadIdx.x < 256 && cbase + threadIdx.x < dx) {
-    atomicAdd(&dye_add[(int64_t)b * dx + cbase + threadIdx.x], dya_acc[threadIdx.x]);
-    atomicAdd(&dye_mul[(int64_t)b * dx + cbase + threadIdx.x], dym_acc[threadIdx.x]);
+}
+
+// Adds the key groups' partial dQ / dye_add / dye_mul in index order (fixed order: reproducible).
+__global__ __launch_bounds__(256) void edge_attn_bwd_reduce_kernel(const float* __restrict__ dq_part, int64_t dq_group_stride,
+                                                                   const float* __restrict__ dye_part, int64_t dye_group_stride,
+                                                                   float* __restrict__ dQ, float* __restrict__ dye_add,
+                                                                   float* __restrict__ dye_mul, int b0, int nb, int n, int dx,
+                                                                   int ldq, int n_kg) {
+  const int64_t rows = (int64_t)nb * n, total = rows * dx, extra = (int64_t)nb * 2 * dx;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + extra; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < total) {
+      float s = 0.f;
+      for (int g = 0; g < n_kg; ++g) s += dq_part[(int64_t)g * dq_group_stride + e];
+      const int64_t row = e / dx; const int c = (int)(e - row * dx);
+      dQ[((int64_t)b0 * n + row) * ldq + c] = s;
+    } else {
+      const int64_t r = e - total;
+      float s = 0.f;
+      for (int g = 0; g < n_kg; ++g) s += dye_part[(int64_t)g * dye_group_stride + r];
+      const int64_t bl = r / (2 * dx); const int rem = (int)(r - bl * 2 * dx);
+      if (rem < dx) dye_add[((int64_t)b0 + bl) * dx + rem] = s;
+      else dye_mul[((int64_t)b0 + bl) * dx + rem - dx] = s;
+    }
   }
 }
 
@@ -271,28 +295,54 @@ int mbvae_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t 
 
 // Gradients of the above given dP [bs,n,n,dx] and dwV [bs,n,dx] (dense).
 // Writes dE1,dE2 (rows lde apart, like E1,E2), dQ,dK,dV (rows ldq apart, like Q,K,V), dye_add,dye_mul [bs,dx].
+// workspace: partial sums of the key groups (16 keys each); mbvae_edge_attn_bwd_workspace(bs, n, dx) bytes let the whole
+// batch run in one launch, less makes the call walk over the batch in chunks of graphs (at least one graph's worth is
+// needed; none at all when n <= 16).  Bitwise reproducible.
+int64_t mbvae_edge_attn_bwd_workspace(int64_t bs, int64_t n, int64_t dx) {
+  const int64_t n_kg = (n + 7) / 8;                 // (sized for the smaller of the two key-group widths)
+  return n <= 16 ? 0 : (int64_t)sizeof(float) * n_kg * bs * (n * dx + 2 * dx);
+}
+
 int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
                         int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
                         const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
                         float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
-                        float scale, hipStream_t stream) {
+                        float scale, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
-  if (bs <= 0 || n <= 0 || dx <= 0 || (dx & 3)) return MBVAE_EUNSUPPORTED;
-  if (ldq < dx || lde < dx || (ldq & 3) || (lde & 3) || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
-  if (bs > 65535 || n > 16 * 65535) return MBVAE_EUNSUPPORTED;
+  if (bs <= 0 || n <= 0 || dx <= 0) return MBVAE_EUNSUPPORTED;
+  if (ldq < dx || lde < dx || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
+  if (bs > 0x7fffffff / 64 || n > 0x7fffffff / 64 || dx > 0x7fffffff / 4) return MBVAE_EUNSUPPORTED;
   const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};
-  for (const void* p : ptrs) if (!p || !ea_aligned(p)) return MBVAE_EINVAL;
+  for (const void* p : ptrs) if (!p) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
-  // dQ is accumulated with float adds; with ldq > dx the gaps between its rows (dK/dV blocks) are zeroed too and
-  // then overwritten by the kernel's plain stores
-  if (hipMemsetAsync(dQ, 0, sizeof(float) * ((bs * n - 1) * ldq + dx), stream) != hipSuccess) return MBVAE_ELAUNCH;
-  if (hipMemsetAsync(dye_add, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
-  if (hipMemsetAsync(dye_mul, 0, sizeof(float) * bs * dx, stream) != hipSuccess) return MBVAE_ELAUNCH;
-  constexpr int NW = 8, ROWS = 32;
-  dim3 grid((unsigned)((dx + 255) / 256), (unsigned)((n + 2 * NW - 1) / (2 * NW)), (unsigned)bs);
-  hipLaunchKernelGGL((edge_attn_bwd_kernel<NW, ROWS>), grid, dim3(64 * NW), 0, stream, Q, K, V, E1, E2, ye_mul, mask,
-                     wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul, (int)n, (int)dx, scale, (int)ldq,
-                     (int)lde);
+  const int KPW = mbvae_opt(MBVAE_OPT_EA_KEYS) == 8 ? 8 : 16;
+  const int n_kg = (int)((n + KPW - 1) / KPW), n_cq = (int)((dx + 63) / 64);
+  const int64_t per_graph = (int64_t)sizeof(float) * n_kg * (n * dx + 2 * dx);
+  int64_t chunk = bs;
+  if (n_kg > 1) {
+    if (!workspace || ws_bytes < per_graph) return MBVAE_EINVAL;
+    chunk = std::min<int64_t>(bs, ws_bytes / per_graph);
+  }
+  for (int64_t b0 = 0; b0 < bs; b0 += chunk) {
+    const int nb = (int)std::min<int64_t>(chunk, bs - b0);
+    float* dq_part = n_kg > 1 ? (float*)workspace : dQ + b0 * n * ldq;
+    const int64_t dq_stride = n_kg > 1 ? (int64_t)nb * n * dx : 0;
+    float* dye_part = n_kg > 1 ? (float*)workspace + (int64_t)n_kg * dq_stride : nullptr;
+    const int64_t dye_stride = (int64_t)nb * 2 * dx;
+    const int64_t waves = (int64_t)nb * n_kg * n_cq;
+    const bool pf = mbvae_opt(MBVAE_OPT_NO_EA_PREFETCH) == 0;   // measured at bs=256, n=64, dx=256: 16 keys + prefetch is fastest
+    auto kern = KPW == 8 ? (pf ? edge_attn_bwd_kernel<8, true> : edge_attn_bwd_kernel<8, false>)
+                         : (pf ? edge_attn_bwd_kernel<16, true> : edge_attn_bwd_kernel<16, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Q, K, V, E1, E2,
+                       ye_mul, mask, wV, lse, dP, dwV, dE1, dE2, dK, dV, dq_part, n_kg > 1 ? dx : ldq, dq_stride, dye_part,
+                       dye_stride, dye_add, dye_mul, (int)b0, nb, (int)n, (int)dx, scale, (int)ldq, (int)lde, n_kg, n_cq);
+    if (n_kg > 1) {
+      const int64_t total = (int64_t)nb * n * dx + (int64_t)nb * 2 * dx;
+      const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL(edge_attn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dq_part, dq_stride, dye_part,
+                         dye_stride, dQ, dye_add, dye_mul, (int)b0, nb, (int)n, (int)dx, (int)ldq, n_kg);
+    }
+  }
   return mbvae_launch_status();
 }
 

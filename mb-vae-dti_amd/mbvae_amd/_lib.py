@@ -22,7 +22,8 @@ SIGNATURES = {
     "mbvae_linear_bwd_input_add": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _P],
     "mbvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
     "mbvae_edge_attn_fwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 6 + [_L, _L, _L, _F, _P],
-    "mbvae_edge_attn_bwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P],
+    "mbvae_edge_attn_bwd_workspace": [_L, _L, _L],
+    "mbvae_edge_attn_bwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P, _L, _P],
     "mbvae_edge_fused_fwd": [_P] * 6 + [_L] + [_P] * 10 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_ffn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],
@@ -46,7 +47,7 @@ SIGNATURES = {
     "mbvae_apply_noise": [_P] * 12 + [_L, _L, _L, _L, _P],
     "mbvae_reverse_sample": [_P] * 18 + [_L, _L, _L, _L, _P],
 }
-_RET64 = {"mbvae_ln_residual_bwd_workspace", "mbvae_masked_ce_workspace", "mbvae_kl_workspace"}
+_RET64 = {"mbvae_edge_attn_bwd_workspace", "mbvae_ln_residual_bwd_workspace", "mbvae_masked_ce_workspace", "mbvae_kl_workspace"}
 
 _STATUS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 _lib = None

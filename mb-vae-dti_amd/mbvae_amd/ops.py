@@ -22,7 +22,7 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def workspace(device, nbytes=96 << 20):
+def workspace(device, nbytes=160 << 20):
     """Per-device scratch buffer shared by all kernels (they are serialised on the stream)."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     ws = _ws_cache.get(key)
@@ -250,10 +250,11 @@ def _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV):
     dQKV = torch.empty_like(QKV)
     dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
     q, e, dq, de = QKV.data_ptr(), E12.data_ptr(), dQKV.data_ptr(), dE12.data_ptr()
+    ws = workspace(wV.device)
     _lib.call("mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
               ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
               de, de + 4 * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, scale,
-              _stream())
+              ws.data_ptr(), ws.numel(), _stream())
     return dQKV, dE12, dya, dym
 
 

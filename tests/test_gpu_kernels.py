@@ -820,6 +820,38 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
         assert_close(a, b_, rtol=1e-5, what="grads fused vs separate")
 
 
+def test_train_step_gradients_are_bitwise_reproducible():
+    """Two runs of the same denoiser step (same weights, data, dropout seeds) at the benchmark widths give bit-identical
+    losses and gradients: no kernel on the path accumulates with floating-point atomics (the attention backward sums
+    its per-key-group partials in a fixed order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd import ops as O
+    from mbvae_amd.graph_transformer import GraphTransformer
+    from mbvae_amd.trainstep import CFG3, synthetic_graphs
+    cfg = dict(CFG3); cfg["n_layers"] = 2
+    torch.manual_seed(3)
+    net = GraphTransformer(**cfg).cuda().train()
+    g = torch.Generator().manual_seed(5)
+    bs, n = 16, 64
+    sizes = torch.randint(20, n + 1, (bs,), generator=g); sizes[0] = n
+    X0, E0, mask = synthetic_graphs(bs, n, "cuda", g, sizes=sizes)
+    Xin = torch.cat((X0, torch.randn(bs, n, 8, generator=g).cuda() * mask.unsqueeze(-1)), 2)
+    yin = torch.randn(bs, 1037, generator=g).cuda()
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(11)                            # same dropout seeds
+        out = net(Xin, E0, yin, mask)
+        lX, _ = O.masked_ce(out.X, X0); lE, _ = O.masked_ce(out.E, E0)
+        loss = lX + 5 * lE + out.y.pow(2).mean()
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), f"gradient of {k} differs between two identical runs"
+
+
 def test_grad_sync_rccl_world1_matches_plain_step():
     """The bucketed gradient all-reduce over RCCL (world size 1 on the single test GPU) leaves the train step unchanged:
     flat-bucket gradient views, async all-reduce from hooks, divide, zero_grad re-arming."""
