@@ -1072,6 +1072,162 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
   return mbvae_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Small-output products with a long reduction (the global-feature path and the encoder MLPs: a few hundred rows,
+// K ~ 1000): too few 64x64 tiles to fill the chip, so the generic kernel would split the reduction over workgroups
+// and sum the partials in a second launch.  Here a workgroup owns ONE 32x32 output tile and its four waves split the
+// reduction among themselves (64-wide groups, round robin); the four partial tiles meet in LDS and are added in wave
+// order, so the result is reproducible, no workspace is needed and nothing else is launched.  Operands go straight
+// from global memory into MFMA operand registers, whatever their layout:
+//   reduction index contiguous (x [M,K], W [N,K]):   lane (row r, half h) reads 32 consecutive indices 32h .. 32h+31
+//   output index contiguous (W [K,N], dy / x [R,.]): lane (col r, half h) reads one word of each of the rows 32h .. 32h+31
+// and step s of a group multiplies indices s (lower half-wave) and 32+s (upper half-wave) for both operands.
+template <bool A_KC, bool B_KC, bool GATE>
+__global__ __launch_bounds__(256) void smallm_gemm_kernel(GemmArgs g) {
+  __shared__ float red[4][16][64];
+  __shared__ float csum[4][32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = (g.N + 31) / 32;
+  const int m0 = ((int)blockIdx.x / tiles_n) * 32, n0 = ((int)blockIdx.x % tiles_n) * 32;
+  const int K = g.K;
+  const int groups = (K + 63) / 64;
+  const int mine = (groups - wave + 3) / 4;               // groups wave, wave + 4, ...
+  const int am = min(m0 + r, g.M - 1), bn = min(n0 + r, g.N - 1);     // clamped: surplus rows / columns are never stored
+  const bool want_colsum = g.colsum != nullptr && n0 == 0;
+
+  float a[2][32], b[2][32], gt[2][32];
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  float cs = 0.f;
+
+  // Register slot 4 p + e of a group holds reduction index 8 p + 4 h + e (p < 8, e < 4): step (p, e) multiplies index
+  // 8p + e in the lower half-wave with 8p + 4 + e in the upper one, for both operands.  With this pairing the two
+  // half-waves of a reduction-contiguous operand read ADJACENT 16-byte pieces of a row (one cache line per row and
+  // instruction instead of two), and an output-contiguous operand is addressed as a wave-uniform row pointer plus a
+  // per-lane 32-bit offset.  K % 8 == 0 (checked by the host): a step is valid or invalid as a whole.
+  const unsigned a_lane = A_KC ? (unsigned)(4 * h) : (unsigned)(4 * h) * (unsigned)g.lda + (unsigned)am;
+  const unsigned b_lane = B_KC ? (unsigned)(4 * h) : (unsigned)(4 * h) * (unsigned)g.ldb + (unsigned)bn;
+  const float* a_row = A_KC ? g.A + (int64_t)am * g.lda : g.A;
+  const float* g_row = A_KC ? g.a_gate + (int64_t)am * g.lda : g.a_gate;
+  const float* b_row = B_KC ? g.B + (int64_t)bn * g.ldb : g.B;
+  // requests group q's operand words (no waits); steps past K re-read the last valid one and are zeroed in prep()
+  auto fetch = [&](int q, int S) {
+    const int k0 = (wave + 4 * min(q, mine - 1)) * 64;      // wave-uniform
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int kp = min(k0 + 8 * p, K - 8);                // wave-uniform
+      if (A_KC) {
+        const float4 t = *reinterpret_cast<const float4*>(a_row + kp + a_lane);
+        a[S][4 * p] = t.x; a[S][4 * p + 1] = t.y; a[S][4 * p + 2] = t.z; a[S][4 * p + 3] = t.w;
+        if (GATE) {
+          const float4 u = *reinterpret_cast<const float4*>(g_row + kp + a_lane);
+          gt[S][4 * p] = u.x; gt[S][4 * p + 1] = u.y; gt[S][4 * p + 2] = u.z; gt[S][4 * p + 3] = u.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* rowp = a_row + (int64_t)(kp + e) * g.lda;      // wave-uniform row base
+          a[S][4 * p + e] = rowp[a_lane];
+          if (GATE) gt[S][4 * p + e] = (g_row + (int64_t)(kp + e) * g.lda)[a_lane];
+        }
+      }
+      if (B_KC) {
+        const float4 t = *reinterpret_cast<const float4*>(b_row + kp + b_lane);
+        b[S][4 * p] = t.x; b[S][4 * p + 1] = t.y; b[S][4 * p + 2] = t.z; b[S][4 * p + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[S][4 * p + e] = (b_row + (int64_t)(kp + e) * g.ldb)[b_lane];
+      }
+    }
+    asm volatile("" : : : "memory");
+  };
+  // operand prologue in place (gate, scale, zero past the end of the reduction) and the bias gradient's column sums
+  auto prep = [&](int q, int S) {
+    const int k0 = (wave + 4 * q) * 64;
+    const bool live = q < mine;
+    const bool full = live && k0 + 64 <= K;
+    if (full && !GATE && g.a_gate_scale == 1.f) {
+      if (want_colsum) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) cs += a[S][s];
+      }
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const bool in = live && k0 + 8 * (s >> 2) < K;        // wave-uniform
+      float v = a[S][s];
+      if (GATE && !(gt[S][s] > 0.f)) v = 0.f;
+      v = in ? v * g.a_gate_scale : 0.f;                  // selects: a re-read word must not count
+      a[S][s] = v;
+      if (!in) b[S][s] = 0.f;
+      cs += v;
+    }
+  };
+  auto mma = [&](int S) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][s], b[S][s], acc, 0, 0, 0);
+  };
+
+  if (mine > 0) {
+    fetch(0, 0);
+    for (int q = 0; q < mine; q += 2) {
+      fetch(q + 1, 1);
+      prep(q, 0);
+      mma(0);
+      fetch(q + 2, 0);
+      prep(q + 1, 1);                                     // (a group past the end is zeroed)
+      mma(1);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) red[wave][v][lane] = acc[v];
+  cs += __shfl_xor(cs, 32, 64);
+  if (h == 0) csum[wave][r] = cs;
+  __syncthreads();
+  // the four partial tiles are added in wave order; C/D layout: col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int v = wave * 4 + u;
+    const float sum = ((red[0][v][lane] + red[1][v][lane]) + red[2][v][lane]) + red[3][v][lane];
+    const int row = m0 + (v & 3) + 8 * (v >> 2) + 4 * h, col = n0 + r;
+    if (row < g.M && col < g.N) {
+      float o = sum;
+      if (g.bias) o += g.bias[col];
+      if (g.act == 1) o = fmaxf(o, 0.f);
+      if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
+      g.C[(int64_t)row * g.ldc + col] = o;
+    }
+  }
+  if (want_colsum && tid < 32 && m0 + tid < g.M)
+    g.colsum[m0 + tid] = ((csum[0][tid] + csum[1][tid]) + csum[2][tid]) + csum[3][tid];
+}
+
+// MBVAE_EUNSUPPORTED when the shape is not one of these (the caller then uses the generic kernel).
+template <bool A_KC, bool B_KC>
+static int smallm_try(const GemmArgs& g, hipStream_t stream) {
+  if (mbvae_opt(MBVAE_OPT_NO_SMALLM)) return MBVAE_EUNSUPPORTED;
+  if (g.a_mask_mode != MBVAE_MASK_NONE || g.c_mask_mode != MBVAE_MASK_NONE || g.accumulate || g.addend) return MBVAE_EUNSUPPORTED;
+  const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  const int64_t tiles32 = (int64_t)((g.M + 31) / 32) * ((g.N + 31) / 32);
+  // The regime where the generic kernel would split the reduction (few big tiles, a reduction worth splitting), and of
+  // that the part where this kernel measured faster (tools/smallm_probe.py): at most one workgroup per compute unit,
+  // and either enough of them to fill the chip or a short reduction.  Operand reuse of a 32x32 tile is low (8 flops per
+  // byte from L2), so with two or more rounds of workgroups the 64x64 tiles of the generic kernel win.
+  if (tiles64 >= 256 || g.K < 128 || (g.K & 7)) return MBVAE_EUNSUPPORTED;
+  if (tiles32 > mbvae_num_cus() || g.K > 2048 || !(tiles32 >= mbvae_num_cus() / 2 || g.K <= 512)) return MBVAE_EUNSUPPORTED;
+  if ((int64_t)4 * g.lda + g.M >= 0x7fffffff || (int64_t)4 * g.ldb + g.N >= 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (A_KC && ((((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) || (g.lda & 3) || (g.K & 3))) return MBVAE_EUNSUPPORTED;
+  if (B_KC && (((uintptr_t)g.B & 15) || (g.ldb & 3) || (g.K & 3))) return MBVAE_EUNSUPPORTED;
+  const dim3 grid((unsigned)tiles32), block(256);
+  if (g.a_gate) hipLaunchKernelGGL((smallm_gemm_kernel<A_KC, B_KC, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((smallm_gemm_kernel<A_KC, B_KC, false>), grid, block, 0, stream, g);
+  return mbvae_launch_status();
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
@@ -1082,6 +1238,10 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
     if (g.addend) return MBVAE_EUNSUPPORTED;       // the caller adds it with a separate pass
   } else if (!B_KC) {
     const int st = tswgrad_try(g, workspace, ws_bytes, stream);
+    if (st != MBVAE_EUNSUPPORTED) return st;
+  }
+  {
+    const int st = smallm_try<A_KC, B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
   }
   int BM, BN;

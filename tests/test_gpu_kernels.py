@@ -44,6 +44,9 @@ def ragged_mask(bs, n, gen):
     (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"), (16 * 64 * 64, 128, 128, 1, "edge"),
     # fused e_mul|e_add projection and its gradients (weights up to 128 KB resident in LDS)
     (16 * 64 * 64, 64, 512, 0, "edge"),
+    # few output tiles, long reduction: one 32x32 tile per workgroup, the reduction split over its four waves
+    (256, 4170, 512, 0, "none"), (256, 1024, 2048, 1, "none"), (256, 256, 1024, 0, "none"), (32, 2048, 512, 1, "none"),
+    (256, 2048, 100, 1, "none"), (200, 1000, 72, 0, "none"), (256, 512, 128, 1, "none"), (48, 136, 1024, 0, "none"),
 ])
 def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     g = torch.Generator().manual_seed(M + K + N)
