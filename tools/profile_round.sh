@@ -1,10 +1,14 @@
+# Profiles of one round (GPU box): kernel trace of the bench, and three counter passes over tools/traffic_probe.py
+# (HBM reads, HBM writes, matrix-core / vector-unit busy cycles).  usage: bash tools/profile_round.sh <tag>
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01e
+O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python3 $R/bench.py --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 export TRAFFIC_MANIFEST=$O/manifest.json
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/tools/traffic_probe.py > $O/fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/tools/traffic_probe.py > $O/write.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -- python3 $R/tools/traffic_probe.py > $O/sq.log 2>&1
 ls $O $O/kt
