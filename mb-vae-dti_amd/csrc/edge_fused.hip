@@ -31,7 +31,10 @@ struct EdgeFusedArgs {
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <bool WRITE_E12>
+// SPLIT: the projection runs on the bf16 matrix pipeline (six bf16 MFMAs per fp32 product, see mbvae_split8): the
+// lane's W12 slice is split once into three bf16 planes (96 registers instead of 64), the E rows are split in
+// registers right before their products, one split per 16 reduction indices shared by the E1 and the E2 tile.
+template <bool WRITE_E12, bool SPLIT>
 __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   extern __shared__ __align__(16) float ef_kv[];   // K rows [64][256], then V rows [64][256]
   float* Ks = ef_kv;
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   // B operands: step (p, e) of a tile multiplies reduction index 32h + 4p + e (the A registers hold 32 consecutive
   // reduction indices of the lane's row), so the lane keeps W12[c][32h .. 32h+31] and W12[256 + c][32h .. 32h+31]
   float w1[32], w2[32];
+  MbvaeSplit3 s1[4], s2[4];                          // SPLIT: octet o = reduction indices 32h + 8o .. + 7
   {
     const float* p1 = a.W + (int64_t)c * 64 + 32 * h;
     const float* p2 = a.W + (int64_t)(256 + c) * 64 + 32 * h;
@@ -54,6 +58,13 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const float4 t = ef_ld4(p1 + 4 * q), u = ef_ld4(p2 + 4 * q);
       w1[4 * q] = t.x; w1[4 * q + 1] = t.y; w1[4 * q + 2] = t.z; w1[4 * q + 3] = t.w;
       w2[4 * q] = u.x; w2[4 * q + 1] = u.y; w2[4 * q + 2] = u.z; w2[4 * q + 3] = u.w;
+    }
+    if (SPLIT) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        s1[o] = mbvae_split8(w1[8 * o], w1[8 * o + 1], w1[8 * o + 2], w1[8 * o + 3], w1[8 * o + 4], w1[8 * o + 5], w1[8 * o + 6], w1[8 * o + 7]);
+        s2[o] = mbvae_split8(w2[8 * o], w2[8 * o + 1], w2[8 * o + 2], w2[8 * o + 3], w2[8 * o + 4], w2[8 * o + 5], w2[8 * o + 6], w2[8 * o + 7]);
+      }
     }
   }
   const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const int64_t qrow = node + i0 + ii;                                                             \
       const int j = min(32 * mt + r, n - 1);                                                           \
       const float* src = a.E + ((qrow * n + j) * 64 + 32 * h);                                         \
-      _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = ef_ld4(src + 4 * p);                    \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[SPLIT ? 0 : S][p] = ef_ld4(src + 4 * p);        \
       qv[S] = a.Q[(pnode + i0 + ii) * ldq + c];                                                        \
       asm volatile("" : : : "memory");       /* issue the loads here, do not sink them to their use */ \
     }
@@ -132,10 +143,31 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const bool qi_ok = (kmask >> i) & 1ull;                                                          \
       const unsigned km32 = (unsigned)(kmask >> (32 * mt));                                            \
       if (mt == 0) { m_run = -INFINITY; l_run = 0.f; av_run = 0.f; }                                   \
+      if (SPLIT && !(qi_ok && km32 != 0u)) EF_FETCH((t) + 1, 1 - S)   /* no products here: request the next tile whole */ \
       if (WRITE_E12 || (qi_ok && km32 != 0u)) {    /* inference: a tile without a valid pair is skipped */ \
       f32x16 acc1, acc2;                                                                               \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
-      if (qi_ok && km32 != 0u) {                   /* a tile without a valid (query, key) pair needs no products */ \
+      if (SPLIT && qi_ok && km32 != 0u) {                                                              \
+        /* ONE operand buffer: an octet is dead once split, so the next tile's octet is requested into the same     \
+           registers right there and has the rest of this tile (products, softmax, stores) to arrive */              \
+        const int tn = min((t) + 1, T - 1);                                                            \
+        const int iin = RTq == 2 ? tn >> 1 : tn, mtn = RTq == 2 ? tn & 1 : 0;                          \
+        const float* nsrc = a.E + (((node + i0 + iin) * n + min(32 * mtn + r, n - 1)) * 64 + 32 * h);  \
+        qv[1 - S] = a.Q[(pnode + i0 + iin) * ldq + c];                                                 \
+        _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                \
+          float4 t4 = ra[0][2 * o], u4 = ra[0][2 * o + 1];                                             \
+          asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory"); \
+          const MbvaeSplit3 as = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);         \
+          ra[0][2 * o] = ef_ld4(nsrc + 8 * o); ra[0][2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);            \
+          asm volatile("" : : : "memory");                                                             \
+          acc1 = MBVAE_MFMA_BF16(as.lo, s1[o].hi, acc1);   acc2 = MBVAE_MFMA_BF16(as.lo, s2[o].hi, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(as.hi, s1[o].lo, acc1);   acc2 = MBVAE_MFMA_BF16(as.hi, s2[o].lo, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(as.mid, s1[o].mid, acc1); acc2 = MBVAE_MFMA_BF16(as.mid, s2[o].mid, acc2); \
+          acc1 = MBVAE_MFMA_BF16(as.mid, s1[o].hi, acc1);  acc2 = MBVAE_MFMA_BF16(as.mid, s2[o].hi, acc2);  \
+          acc1 = MBVAE_MFMA_BF16(as.hi, s1[o].mid, acc1);  acc2 = MBVAE_MFMA_BF16(as.hi, s2[o].mid, acc2);  \
+          acc1 = MBVAE_MFMA_BF16(as.hi, s1[o].hi, acc1);   acc2 = MBVAE_MFMA_BF16(as.hi, s2[o].hi, acc2);   \
+        }                                                                                              \
+      } else if (qi_ok && km32 != 0u) {            /* a tile without a valid (query, key) pair needs no products */ \
         _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                \
           float4 t4 = ra[S][p];                                                                        \
           asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");              \
@@ -235,9 +267,9 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
 
     EF_FETCH(0, 0)
     for (int t = 0; t < T; t += 2) {
-      EF_FETCH(t + 1, 1)
+      if (!SPLIT) EF_FETCH(t + 1, 1)
       EF_TILE(t, 0)
-      EF_FETCH(t + 2, 0)
+      if (!SPLIT) EF_FETCH(t + 2, 0)
       EF_TILE(t + 1, 1)
       // keep the eight waves within two tiles of each other: they all read the same E rows, and a wave that falls
       // behind finds them evicted from L1/L2 and fetches them from HBM again (measured: E read 2.7 times).
@@ -670,9 +702,17 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
                   work_counter, node_off, graph_order};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
-  auto k = E12 ? edge_fused_fwd_kernel<true> : edge_fused_fwd_kernel<false>;
-  if (!(E12 ? MBVAE_ALLOW_BIG_LDS(edge_fused_fwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_fused_fwd_kernel<false>)))
-    return MBVAE_ELAUNCH;
+  const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+  void (*k)(EdgeFusedArgs);
+  bool lds_ok;
+  if (split) {
+    k = E12 ? edge_fused_fwd_kernel<true, true> : edge_fused_fwd_kernel<false, true>;
+    lds_ok = E12 ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, true>));
+  } else {
+    k = E12 ? edge_fused_fwd_kernel<true, false> : edge_fused_fwd_kernel<false, false>;
+    lds_ok = E12 ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, false>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, false>));
+  }
+  if (!lds_ok) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();

@@ -459,7 +459,13 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 //    flight while the wave already multiplies its next task.
 //  * The wait for a group's operand loads is pinned right after the previous group's MFMAs and BEFORE the epilogue
 //    stores; placed after them it would have to drain the stores first.
-template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false>
+//
+// SPLIT: the same schedule on the bf16 matrix pipeline (see mbvae_split8: six bf16 MFMAs per fp32 product).  The
+// weights are split ONCE, while they are staged, into three bf16 planes laid out [plane][n][K + 8] (the 16-byte pad
+// makes the MFMA B-operand fetch - lane (n, h) reads the 8 consecutive reduction indices of its octet, one
+// ds_read_b128 per plane - conflict-free); the A rows are split in registers right before their MFMAs, one split per
+// 16 reduction indices, shared by the task's TN column tiles.  6 bytes of LDS per weight: K * N <= 25600.
+template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   constexpr int NT = 64 * WAVES;
   const int N = g.N, LDB = N + 1;
@@ -469,7 +475,23 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic on the scalar unit
   const int r = lane & 31, h = lane >> 5;
   const int K = g.K;
-  if (B_KC) {
+  const int LDK = K + 8;                           // SPLIT: bf16 elements per weight column
+  unsigned short* Bp = reinterpret_cast<unsigned short*>(ts2_smem);   // SPLIT: [3][N][LDK]
+  if (SPLIT) {
+    for (int e = tid; e < N * K; e += NT) {
+      int n, k;
+      float w;
+      if (B_KC) { n = e / K; k = e - n * K; w = g.B[(int64_t)n * g.ldb + k]; }
+      else { k = e / N; n = e - k * N; w = g.B[(int64_t)k * g.ldb + n]; }
+      const unsigned u = __float_as_uint(w);
+      const float r1 = w - __uint_as_float(u & 0xffff0000u);
+      const unsigned v = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(v & 0xffff0000u);
+      Bp[n * LDK + k] = (unsigned short)(u >> 16);
+      Bp[(N + n) * LDK + k] = (unsigned short)(v >> 16);
+      Bp[(2 * N + n) * LDK + k] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+  } else if (B_KC) {
     for (int e = tid; e < N * K; e += NT) { const int n = e / K, k = e - n * K; Bs[k * LDB + n] = g.B[(int64_t)n * g.ldb + k]; }
   } else {
     for (int e = tid; e < N * K; e += NT) { const int k = e / N, n = e - k * N; Bs[k * LDB + n] = g.B[(int64_t)k * g.ldb + n]; }
@@ -563,7 +585,28 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
     }                                                                                                  \
   }
 #define TS2_MMA(q, S)                                                                                 \
-  {                                                                                                   \
+  if (SPLIT) {                                                                                        \
+    TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
+    const unsigned short* Bg = Bp + (cb * (32 * TN) + r) * LDK + gi * 64 + 32 * h;                     \
+    const int plane = N * LDK;                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {          /* 16 reduction indices per step: octet c of each half */ \
+      const MbvaeSplit3 a = mbvae_split8(ra[S][2 * c].x, ra[S][2 * c].y, ra[S][2 * c].z, ra[S][2 * c].w,   \
+                                         ra[S][2 * c + 1].x, ra[S][2 * c + 1].y, ra[S][2 * c + 1].z, ra[S][2 * c + 1].w); \
+      mbvae_bf16x8 bh[TN], bm[TN], bl[TN];                                                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+        const unsigned short* bp = Bg + j * 32 * LDK + 8 * c;                                          \
+        bh[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp);                                            \
+        bm[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + plane);                                    \
+        bl[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + 2 * plane);                                \
+      }                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.lo, bh[j], acc[j]);    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bl[j], acc[j]);    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bm[j], acc[j]);   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bh[j], acc[j]);   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bm[j], acc[j]);    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bh[j], acc[j]);    \
+    }                                                                                                  \
+  } else {                                                                                            \
     TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
     const float* Bg = Bs + (gi * 64 + 32 * h) * LDB + cb * (32 * TN) + r;                              \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
@@ -671,21 +714,29 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
   if (!mbvae_opt(MBVAE_OPT_NO_TSGEMM2) && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
       !(g.addend && g.drop_p > 0.f) && (int64_t)g.M * g.ldc < 0x3fffffff) {
-    const size_t smem2 = sizeof(float) * (size_t)g.K * (g.N + 1);
     const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
     // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
     const bool wide = g.N % 128 == 0 && !g.a_gate && !g.addend;
     const int waves = 8;
-    void (*k)(GemmArgs);
-    if (wide) k = tsgemm2_kernel<4, B_KC, false, 8>;
-    else if (g.addend) k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8, true> : tsgemm2_kernel<2, B_KC, false, 8, true>;
-    else k = g.a_gate ? tsgemm2_kernel<2, B_KC, true, 8> : tsgemm2_kernel<2, B_KC, false, 8>;
-    bool lds_ok;
-    if (wide) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<4, B_KC, false, 8>));
-    else if (g.addend && g.a_gate) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, true, 8, true>));
-    else if (g.addend) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, false, 8, true>));
-    else if (g.a_gate) lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, true, 8>));
-    else lds_ok = MBVAE_ALLOW_BIG_LDS((tsgemm2_kernel<2, B_KC, false, 8>));
+    // bf16-pipeline variant where the three weight planes fit in LDS
+    const size_t smem3 = 2 * 3 * (size_t)g.N * (g.K + 8);
+    const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && smem3 <= MBVAE_LDS_LIMIT;
+    const size_t smem2 = split ? smem3 : sizeof(float) * (size_t)g.K * (g.N + 1);
+    void (*k)(GemmArgs) = nullptr;
+    bool lds_ok = false;
+#define TS2_PICK(cond, ...)                                                                                         \
+    if (k == nullptr && (cond)) { k = __VA_ARGS__; lds_ok = MBVAE_ALLOW_BIG_LDS((__VA_ARGS__)); }
+    TS2_PICK(split && wide, tsgemm2_kernel<4, B_KC, false, 8, false, true>)
+    TS2_PICK(split && g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true, true>)
+    TS2_PICK(split && g.addend, tsgemm2_kernel<2, B_KC, false, 8, true, true>)
+    TS2_PICK(split && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, false, true>)
+    TS2_PICK(split, tsgemm2_kernel<2, B_KC, false, 8, false, true>)
+    TS2_PICK(wide, tsgemm2_kernel<4, B_KC, false, 8>)
+    TS2_PICK(g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true>)
+    TS2_PICK(g.addend, tsgemm2_kernel<2, B_KC, false, 8, true>)
+    TS2_PICK(g.a_gate, tsgemm2_kernel<2, B_KC, true, 8>)
+    TS2_PICK(true, tsgemm2_kernel<2, B_KC, false, 8>)
+#undef TS2_PICK
     if (!lds_ok || smem2 > MBVAE_LDS_LIMIT) return MBVAE_ELAUNCH;
     hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
     return mbvae_launch_status();
@@ -985,6 +1036,142 @@ __global__ __launch_bounds__(512) void tswgrad2_kernel(GemmArgs g, int nchunks) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The wave-autonomous weight gradient on the bf16 matrix pipeline (three-way split, six MFMAs per product: see
+// mbvae_split8).  The native fp32 MFMA keeps the kernel above matrix-core bound (63 % MFMA-busy next to a saturated
+// HBM stream); at 2.7x fewer MFMA cycles per product this one waits for HBM only.  The bf16 MFMA reduces over 16 rows
+// per instruction and wants "lane (c, h) holds rows 8h .. 8h+7 of column c": lane (c, h) therefore loads
+// dY[row + 8h + i][p0 + 2c .. +1] and X[row + 8h + i][q0 + 2c .. +1] for i = 0..7 (8-byte loads, 256-byte row
+// segments per half-wave), which ARE the operand octets of the even / odd column tiles once split - no transposition,
+// no LDS, no barrier.  A wave owns one 64 x 64 block of dW; outputs with fewer than eight blocks let the spare waves
+// take every RS-th 16-row group, each (workgroup, row split) writing its own partial for the fixed-order reduction.
+template <int P, int Q, bool GATE>
+__global__ __launch_bounds__(512) void tswgrad3_kernel(GemmArgs g, int nchunks) {
+  constexpr int NBQ = Q / 64, NBLK = (P / 64) * NBQ, RS = 8 / NBLK, GPC = 4;
+  static_assert(P % 64 == 0 && Q % 64 == 0 && NBLK >= 1 && NBLK <= 8 && RS * NBLK == 8, "1, 2, 4 or 8 blocks of 64 x 64");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int blk = wave % NBLK, rs = wave / NBLK;
+  const int wm = blk / NBQ, wn = blk % NBQ;
+  const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+  const int my = (nchunks - bx + G - 1) / G;            // 64-row chunks of this workgroup
+  const int total = (my * GPC - rs + RS - 1) / RS;      // 16-row groups of this wave: rs, rs + RS, ... of the workgroup's
+  const unsigned offA = (unsigned)(8 * h * g.lda + wm * 64 + 2 * c), offB = (unsigned)(8 * h * g.ldb + wn * 64 + 2 * c);
+
+  float2 ra[3][8], rb[3][8], rg[3][8];
+  unsigned ma[3], mb[3];
+  float cs0 = 0.f, cs1 = 0.f;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+#define W3_GROUP(q) (min((q), total - 1) * RS + rs)
+#define W3_FETCH(q, S)                                                                                \
+  {                                                                                                   \
+    const int gq = W3_GROUP(q);                                                                        \
+    const int64_t c0 = (int64_t)(bx + (gq / GPC) * G) * 64;                                            \
+    const int64_t row = c0 + (gq % GPC) * 16;                                                          \
+    mbvae_row_mask_bytes(g.mask, g.a_mask_mode, c0 + lane, g.n_nodes, g.A, ma[S], mb[S]);              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                    \
+      ra[S][i] = *reinterpret_cast<const float2*>(g.A + (row + i) * g.lda + offA);                     \
+      if (GATE) rg[S][i] = *reinterpret_cast<const float2*>(g.a_gate + (row + i) * g.lda + offA);      \
+      rb[S][i] = *reinterpret_cast<const float2*>(g.B + (row + i) * g.ldb + offB);                     \
+    }                                                                                                  \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+#define W3_PREP(q, S)                                                                                 \
+  {                                                                                                   \
+    unsigned late;                                                                                     \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late) : : "memory");                                         \
+    const unsigned long long kb = __ballot(mbvae_mask_keep(g.a_mask_mode, ma[S] | late, mb[S] | late)); \
+    const float sc = (q) < total ? g.a_gate_scale : 0.f;                                               \
+    if (!GATE && kb == ~0ull && sc == 1.f) {           /* nothing to apply: only pin the loads, sum columns */ \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+        float2 v = ra[S][i];                                                                           \
+        float2 b = rb[S][i];                                                                           \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
+        cs0 += v.x; cs1 += v.y;                                                                        \
+        ra[S][i] = v; rb[S][i] = b;                                                                    \
+      }                                                                                                \
+    } else {                                                                                           \
+      const unsigned kbits = (unsigned)(kb >> ((W3_GROUP(q) % GPC) * 16 + 8 * h));   /* bit i: row 8h + i */ \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+        float2 v = ra[S][i];                                                                           \
+        float2 b = rb[S][i];                                                                           \
+        if (GATE) {                                                                                    \
+          if (!(rg[S][i].x > 0.f)) v.x = 0.f;                                                          \
+          if (!(rg[S][i].y > 0.f)) v.y = 0.f;                                                          \
+        }                                                                                              \
+        const float rk = ((kbits >> i) & 1u) ? sc : 0.f;                                               \
+        v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                            \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
+        cs0 += v.x; cs1 += v.y;                                                                        \
+        ra[S][i] = v; rb[S][i] = b;                                                                    \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  // smallest terms first; the four tiles alternate so that consecutive MFMAs never wait on each other's accumulator
+#define W3_TERM(pa, pb)                                                                               \
+    acc[0][0] = MBVAE_MFMA_BF16(a0.pa, b0.pb, acc[0][0]); acc[0][1] = MBVAE_MFMA_BF16(a0.pa, b1.pb, acc[0][1]); \
+    acc[1][0] = MBVAE_MFMA_BF16(a1.pa, b0.pb, acc[1][0]); acc[1][1] = MBVAE_MFMA_BF16(a1.pa, b1.pb, acc[1][1]);
+#define W3_MMA(S)                                                                                     \
+  {                                                                                                   \
+    const MbvaeSplit3 a0 = mbvae_split8(ra[S][0].x, ra[S][1].x, ra[S][2].x, ra[S][3].x, ra[S][4].x, ra[S][5].x, ra[S][6].x, ra[S][7].x); \
+    const MbvaeSplit3 a1 = mbvae_split8(ra[S][0].y, ra[S][1].y, ra[S][2].y, ra[S][3].y, ra[S][4].y, ra[S][5].y, ra[S][6].y, ra[S][7].y); \
+    const MbvaeSplit3 b0 = mbvae_split8(rb[S][0].x, rb[S][1].x, rb[S][2].x, rb[S][3].x, rb[S][4].x, rb[S][5].x, rb[S][6].x, rb[S][7].x); \
+    const MbvaeSplit3 b1 = mbvae_split8(rb[S][0].y, rb[S][1].y, rb[S][2].y, rb[S][3].y, rb[S][4].y, rb[S][5].y, rb[S][6].y, rb[S][7].y); \
+    W3_TERM(lo, hi) W3_TERM(hi, lo) W3_TERM(mid, mid) W3_TERM(mid, hi) W3_TERM(hi, mid) W3_TERM(hi, hi)  \
+  }
+
+  if (total > 0) {
+    W3_FETCH(0, 0)
+    W3_FETCH(1, 1)
+    W3_PREP(0, 0)
+    for (int q = 0; q < total; q += 3) {
+      W3_FETCH(q + 2, 2)
+      W3_MMA(0)
+      W3_PREP(q + 1, 1)
+      W3_FETCH(q + 3, 0)
+      W3_MMA(1)                     /* groups past the end were scaled to zero */
+      W3_PREP(q + 2, 2)
+      W3_FETCH(q + 4, 1)
+      W3_MMA(2)
+      W3_PREP(q + 3, 0)
+    }
+  }
+#undef W3_GROUP
+#undef W3_FETCH
+#undef W3_PREP
+#undef W3_TERM
+#undef W3_MMA
+
+  // ---- partial dW of this (workgroup, row split): tile (i, j) holds rows 64 wm + 2 m + i, columns 64 wn + 2 c + j
+  const int slot = bx * RS + rs;
+  float* part = g.partial + (int64_t)slot * P * Q;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = (v & 3) + 8 * (v >> 2) + 4 * h;
+      const int row = wm * 64 + 2 * m + i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) part[row * Q + wn * 64 + 2 * c + j] = acc[i][j][v];
+    }
+  if (g.partial_colsum != nullptr) {
+    cs0 += __shfl_xor(cs0, 32, 64);
+    cs1 += __shfl_xor(cs1, 32, 64);
+    if (wn == 0 && h == 0) {
+      g.partial_colsum[(int64_t)slot * P + wm * 64 + 2 * c] = cs0;
+      g.partial_colsum[(int64_t)slot * P + wm * 64 + 2 * c + 1] = cs1;
+    }
+  }
+}
+
 // Sums `splits` partial [M,N] results (+ partial column sums) in a fixed order: 4 waves per 64 consecutive outputs,
 // wave z adds the partials z, z+4, ..., the four sums are combined through LDS.
 __global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int splits) {
@@ -1021,6 +1208,32 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0;
   if (!aligned || R < 32768 || R % 32 || P * Q > 32768 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
     return MBVAE_EUNSUPPORTED;
+  // every edge-path shape: the bf16-pipeline kernel (one 64 x 64 block of dW per wave)
+  if (!mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P % 64 == 0 && Q % 64 == 0 &&
+      (int64_t)8 * g.lda + P < 0x7fffffff && (int64_t)8 * g.ldb + Q < 0x7fffffff && workspace != nullptr) {
+    const int nblk = (P / 64) * (Q / 64);
+    if (nblk == 1 || nblk == 2 || nblk == 4 || nblk == 8) {
+      const int nchunks3 = R / 64;
+      const int grid3 = std::min(nchunks3, ts_num_cus());
+      const int slots = grid3 * (8 / nblk);
+      if (ws_bytes >= (int64_t)slots * ((int64_t)P * Q + P) * 4) {
+        g.partial = (float*)workspace;
+        g.partial_colsum = g.colsum ? g.partial + (int64_t)slots * P * Q : nullptr;
+        const bool gate3 = g.a_gate != nullptr;
+        void (*k3)(GemmArgs, int) = nullptr;
+#define TW3_PICK(p, q) if (P == p && Q == q) k3 = gate3 ? tswgrad3_kernel<p, q, true> : tswgrad3_kernel<p, q, false>;
+        TW3_PICK(512, 64) TW3_PICK(256, 64) TW3_PICK(64, 256) TW3_PICK(128, 64) TW3_PICK(64, 128) TW3_PICK(128, 128) TW3_PICK(64, 64)
+        TW3_PICK(64, 512) TW3_PICK(256, 128) TW3_PICK(128, 256)
+#undef TW3_PICK
+        if (k3 != nullptr) {
+          hipLaunchKernelGGL(k3, dim3(grid3), dim3(512), 0, stream, g, nchunks3);
+          const int64_t total3 = (int64_t)P * Q + P;
+          hipLaunchKernelGGL(tswgrad_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, stream, g, slots);
+          return mbvae_launch_status();
+        }
+      }
+    }
+  }
   if (P * Q > 16384 && !(P == 512 && Q == 64 && !g.a_gate)) return MBVAE_EUNSUPPORTED;
   // the widest edge-path gradient (fused e_mul|e_add projection, 512 x 64) runs on the LDS-free kernel: 8 % faster there
   if (!mbvae_opt(MBVAE_OPT_NO_TSWGRAD2) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P == 512 && Q == 64 && !g.a_gate &&

@@ -64,6 +64,11 @@ def test_linear_fwd_bwd(ops, M, K, N, act, mode):
         keep = (mask.unsqueeze(1) & mask.unsqueeze(2)).reshape(M, 1).float()
     xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
     y = F.linear(xr, wr, br)
+    if act:
+        # a pre-activation within rounding of zero may land on either side of the ReLU in two correct fp32
+        # implementations (expected about once per 10^7 outputs); its cotangent is dropped so that the gradient
+        # comparison does not depend on that coin flip
+        cot = cot * (y.detach().abs() > 1e-5)
     y = (F.relu(y) if act else y) * keep
     (y * cot).sum().backward()
     xg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
