@@ -229,6 +229,37 @@ int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float
                          int64_t* Ec, float* Xs, float* Es, float* probX, float* probE, int64_t bs, int64_t n,
                          int64_t cx, int64_t ce, mbvae_stream_t stream);
 
+/* ---- opt-in bf16 STORAGE of the edge block's large activations ------------------------------------------
+ * No counterpart in the reference (which trains in fp32 throughout; its own mixed-precision switch is Lightning's
+ * `precision` flag, mb_vae_dti/training/run.py:642).  The projection output E1|E2 [bs,n,n,2dx], the attention output
+ * P [bs,n,n,dx] (graph_transformer.py:206-267) and the gradients of both are bf16 IN MEMORY (uint16_t = bf16 bits,
+ * round to nearest even on store); weights, biases, every other tensor, all arithmetic and all sums stay fp32.
+ * Same argument meaning as the fp32 entry points they mirror; edge-path shapes only (MBVAE_EUNSUPPORTED otherwise).
+ * Parity bound of the mode: 2e-2 against the fp32 path. */
+int mbvae_edge_fused_fwd_bf16(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                              const float* V, int64_t ldq, const float* ye_add, const float* ye_mul,
+                              const uint8_t* mask, uint16_t* P, float* wV, float* lse, uint16_t* E12, int64_t bs,
+                              int64_t n, int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
+int mbvae_edge_attn_bwd_bf16(const float* Q, const float* K, const float* V, int64_t ldq, const uint16_t* E1,
+                             const uint16_t* E2, int64_t lde, const float* ye_mul, const uint8_t* mask,
+                             const float* wV, const float* lse, const uint16_t* dP, const float* dwV, uint16_t* dE1,
+                             uint16_t* dE2, float* dQ, float* dK, float* dV, float* dye_add, float* dye_mul,
+                             int64_t bs, int64_t n, int64_t dx, float scale, void* workspace, int64_t ws_bytes,
+                             mbvae_stream_t stream);
+/* y (fp32) = rowmask(x (bf16) @ w^T + bias): the e_out projection reading P */
+int mbvae_linear_fwd_bf16(const uint16_t* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                          int64_t M, int64_t K, int64_t N, const uint8_t* mask, int mask_mode, int n_nodes,
+                          mbvae_stream_t stream);
+/* dx = rowmask(dy) @ w (+ addend, fp32, may be NULL): exactly one of dy / dx is bf16 (dy_bf16 / dx_bf16 != 0) */
+int mbvae_linear_bwd_input_bf16(const void* dy, int dy_bf16, int64_t lddy, const float* w, const float* addend,
+                                void* dx, int dx_bf16, int64_t lddx, int64_t M, int64_t K, int64_t N,
+                                const uint8_t* mask, int mask_mode, int n_nodes, mbvae_stream_t stream);
+/* dw = rowmask(dy)^T @ x, db = column sums of rowmask(dy): exactly one of dy / x is bf16 */
+int mbvae_linear_bwd_weight_bf16(const void* dy, int dy_bf16, int64_t lddy, const void* x, int x_bf16, int64_t ldx,
+                                 float* dw, float* db, int64_t M, int64_t K, int64_t N, const uint8_t* mask,
+                                 int mask_mode, int n_nodes, void* workspace, int64_t ws_bytes,
+                                 mbvae_stream_t stream);
+
 /* ---- class-id wire format ------------------------------------------------------------------------------
  * Dense clean graphs from int8 class ids (atoms [bs,n], < 0 = padding; bonds [bs,n,n], 0 = none): the output
  * convention of to_dense + encode_no_edge (mb_vae_dti/training/diffusion/utils.py:90-120, called from

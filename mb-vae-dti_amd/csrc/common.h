@@ -194,4 +194,10 @@ __device__ __forceinline__ MbvaeSplit3 mbvae_split8(float x0, float x1, float x2
   s.lo = __builtin_bit_cast(mbvae_bf16x8, l);
   return s;
 }
+// fp32 -> bf16 bits, round to nearest even (NaN stays a quiet NaN)
+__device__ __forceinline__ unsigned short mbvae_f2bf(float v) {
+  const unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 #define MBVAE_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)

@@ -117,14 +117,16 @@ __global__ __launch_bounds__(64 * ROWS) void edge_attn_fwd_kernel(
 // and a second tiny kernel adds the key groups' partials in index order.  No LDS, no barrier, no atomic: the result
 // is bitwise reproducible from run to run.  The four waves of a workgroup are the four channel quarters of one
 // (graph, key group), so together they read whole 1 KiB rows.
-template <int KPW, bool PREFETCH>
+// BF16: the edge streams (E1, E2, dP in; dE1, dE2 out) are bf16 in memory - the opt-in reduced-precision storage
+// mode; all arithmetic and every sum stay fp32, the outputs are rounded to nearest-even when stored.
+template <int KPW, bool PREFETCH, bool BF16 = false>
 __global__ __launch_bounds__(256) void edge_attn_bwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-    const float* __restrict__ E1, const float* __restrict__ E2,
+    const void* __restrict__ E1v, const void* __restrict__ E2v,
     const float* __restrict__ ye_mul, const uint8_t* __restrict__ mask,
     const float* __restrict__ wV, const float* __restrict__ lse,
-    const float* __restrict__ dP, const float* __restrict__ dwV,
-    float* __restrict__ dE1, float* __restrict__ dE2, float* __restrict__ dK, float* __restrict__ dV,
+    const void* __restrict__ dPv, const float* __restrict__ dwV,
+    void* __restrict__ dE1v, void* __restrict__ dE2v, float* __restrict__ dK, float* __restrict__ dV,
     float* __restrict__ dq_out, int64_t dq_ld, int64_t dq_group_stride,      // dQ itself (one key group) or the partials
     float* __restrict__ dye_out, int64_t dye_group_stride,                   // [group][b][2][dx] (or dye_add|dye_mul ...)
     float* __restrict__ dye_add, float* __restrict__ dye_mul,                // ... written directly when there is one group
@@ -162,22 +164,33 @@ __global__ __launch_bounds__(256) void edge_attn_bwd_kernel(
   // Stream addressing through buffer descriptors: the row base sits in scalar registers, the key offset is a scalar
   // immediate-like operand and only the lane's channel offset is a vector register.  (Flat 64-bit addresses for the
   // 48 loads and 32 stores of a row would by themselves fill the register file.)
-  const int voff = cc * 4;
-  const unsigned e_key = (unsigned)lde * 4u, p_key = (unsigned)dx * 4u;        // bytes from one key's row to the next
+  constexpr int ES = BF16 ? 2 : 4;                 // bytes per stream element
+  const char* E1 = (const char*)E1v; const char* E2 = (const char*)E2v; const char* dP = (const char*)dPv;
+  char* dE1 = (char*)dE1v; char* dE2 = (char*)dE2v;
+  const int voff = cc * ES;
+  const unsigned e_key = (unsigned)lde * ES, p_key = (unsigned)dx * ES;        // bytes from one key's row to the next
+  auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, int soff) -> float {
+    if (BF16) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 2) << 16);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2));
+  };
+  auto st = [&](float v, const __amdgpu_buffer_rsrc_t& rs, int soff) {
+    if (BF16) __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(v), rs, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 2);
+  };
   struct RowRegs { float x1[KPW], x2[KPW], dpv[KPW], q, ls, wv, dwv; };
   // requests one query row's operands (nothing is waited for here)
   auto load_row = [&](int i, RowRegs& r) {
     const int64_t nrow = node + min(i, n - 1);
     const int64_t eoff = (nrow * n + j0) * (int64_t)lde, poff = (nrow * n + j0) * (int64_t)dx;
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(E1 + eoff), 0, nk * (int)e_key, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(E2 + eoff), 0, nk * (int)e_key, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dP + poff), 0, nk * (int)p_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(E1 + eoff * ES), 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(E2 + eoff * ES), 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dP + poff * ES), 0, nk * (int)p_key, 0x00020000);
 #pragma unroll
     for (int t = 0; t < KPW; ++t) {
       const int tt = min(t, nk - 1);               // clamped: the loads stay unconditional
-      r.x1[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, voff, tt * (int)e_key, 2));
-      r.x2[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, voff, tt * (int)e_key, 2));
-      r.dpv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, voff, tt * (int)p_key, 2));
+      r.x1[t] = ld(r1, tt * (int)e_key);
+      r.x2[t] = ld(r2, tt * (int)e_key);
+      r.dpv[t] = ld(rp, tt * (int)p_key);
     }
     r.q = Q[nrow * ldq + cc]; r.ls = lse[nrow * dx + cc]; r.wv = wV[nrow * dx + cc]; r.dwv = dwV[nrow * dx + cc];
     asm volatile("" : : : "memory");               // the loads are issued HERE
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(256) void edge_attn_bwd_kernel(
   auto compute_row = [&](int i, const RowRegs& r) {
     const int64_t nrow = node + i;
     const int64_t eoff = (nrow * n + j0) * (int64_t)lde;
-    const __amdgpu_buffer_rsrc_t w1 = __builtin_amdgcn_make_buffer_rsrc(dE1 + eoff, 0, nk * (int)e_key, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w2 = __builtin_amdgcn_make_buffer_rsrc(dE2 + eoff, 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1 = __builtin_amdgcn_make_buffer_rsrc(dE1 + eoff * ES, 0, nk * (int)e_key, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2 = __builtin_amdgcn_make_buffer_rsrc(dE2 + eoff * ES, 0, nk * (int)e_key, 0x00020000);
     float dq = 0.f;
 #pragma unroll
     for (int t = 0; t < KPW; ++t) {
@@ -196,8 +209,8 @@ __global__ __launch_bounds__(256) void edge_attn_bwd_kernel(
         const float a = ((okbits >> t) & 1u) ? __expf(y - r.ls) : 0.f;
         const float dy = r.dpv[t] * ym + a * r.dwv * (vj[t] - r.wv);
         if (active) {
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy * qk), w1, voff, t * (int)e_key, 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy), w2, voff, t * (int)e_key, 2);
+          st(dy * qk, w1, t * (int)e_key);
+          st(dy, w2, t * (int)e_key);
         }
         const float g = dy * (r.x1[t] + 1.f);
         dq += g * ks[t];
@@ -303,11 +316,11 @@ int64_t mbvae_edge_attn_bwd_workspace(int64_t bs, int64_t n, int64_t dx) {
   return n <= 16 ? 0 : (int64_t)sizeof(float) * n_kg * bs * (n * dx + 2 * dx);
 }
 
-int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
-                        int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
-                        const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
-                        float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
-                        float scale, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+static int edge_attn_bwd_impl(const float* Q, const float* K, const float* V, int64_t ldq, const void* E1, const void* E2,
+                              int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+                              const void* dP, const float* dwV, void* dE1, void* dE2, float* dQ, float* dK,
+                              float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
+                              float scale, void* workspace, int64_t ws_bytes, hipStream_t stream, bool bf16) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0 || dx <= 0) return MBVAE_EUNSUPPORTED;
   if (ldq < dx || lde < dx || ldq > 0x7fffffff || lde > 0x7fffffff) return MBVAE_EINVAL;
@@ -315,7 +328,7 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
   const void* ptrs[] = {Q, K, V, E1, E2, ye_mul, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul};
   for (const void* p : ptrs) if (!p) return MBVAE_EINVAL;
   if (!mask) return MBVAE_EINVAL;
-  const int KPW = mbvae_opt(MBVAE_OPT_EA_KEYS) == 8 ? 8 : 16;
+  const int KPW = (!bf16 && mbvae_opt(MBVAE_OPT_EA_KEYS) == 8) ? 8 : 16;
   const int n_kg = (int)((n + KPW - 1) / KPW), n_cq = (int)((dx + 63) / 64);
   const int64_t per_graph = (int64_t)sizeof(float) * n_kg * (n * dx + 2 * dx);
   int64_t chunk = bs;
@@ -331,8 +344,9 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
     const int64_t dye_stride = (int64_t)nb * 2 * dx;
     const int64_t waves = (int64_t)nb * n_kg * n_cq;
     const bool pf = mbvae_opt(MBVAE_OPT_NO_EA_PREFETCH) == 0;   // measured at bs=256, n=64, dx=256: 16 keys + prefetch is fastest
-    auto kern = KPW == 8 ? (pf ? edge_attn_bwd_kernel<8, true> : edge_attn_bwd_kernel<8, false>)
-                         : (pf ? edge_attn_bwd_kernel<16, true> : edge_attn_bwd_kernel<16, false>);
+    auto kern = bf16 ? edge_attn_bwd_kernel<16, true, true>
+                : KPW == 8 ? (pf ? edge_attn_bwd_kernel<8, true> : edge_attn_bwd_kernel<8, false>)
+                           : (pf ? edge_attn_bwd_kernel<16, true> : edge_attn_bwd_kernel<16, false>);
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Q, K, V, E1, E2,
                        ye_mul, mask, wV, lse, dP, dwV, dE1, dE2, dK, dV, dq_part, n_kg > 1 ? dx : ldq, dq_stride, dye_part,
                        dye_stride, dye_add, dye_mul, (int)b0, nb, (int)n, (int)dx, scale, (int)ldq, (int)lde, n_kg, n_cq);
@@ -344,6 +358,26 @@ int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t 
     }
   }
   return mbvae_launch_status();
+}
+
+int mbvae_edge_attn_bwd(const float* Q, const float* K, const float* V, int64_t ldq, const float* E1, const float* E2,
+                        int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV, const float* lse,
+                        const float* dP, const float* dwV, float* dE1, float* dE2, float* dQ, float* dK,
+                        float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t dx,
+                        float scale, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  return edge_attn_bwd_impl(Q, K, V, ldq, E1, E2, lde, ye_mul, mask, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul,
+                            bs, n, dx, scale, workspace, ws_bytes, stream, false);
+}
+
+// The same with the edge streams stored as bf16: E1, E2, dP are read and dE1, dE2 written as bf16 (lde counts bf16
+// elements); Q, K, V, wV, lse, dwV and every other output stay fp32.
+int mbvae_edge_attn_bwd_bf16(const float* Q, const float* K, const float* V, int64_t ldq, const uint16_t* E1,
+                             const uint16_t* E2, int64_t lde, const float* ye_mul, const uint8_t* mask, const float* wV,
+                             const float* lse, const uint16_t* dP, const float* dwV, uint16_t* dE1, uint16_t* dE2,
+                             float* dQ, float* dK, float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n,
+                             int64_t dx, float scale, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  return edge_attn_bwd_impl(Q, K, V, ldq, E1, E2, lde, ye_mul, mask, wV, lse, dP, dwV, dE1, dE2, dQ, dK, dV, dye_add, dye_mul,
+                            bs, n, dx, scale, workspace, ws_bytes, stream, true);
 }
 
 }  // extern "C"

@@ -34,8 +34,11 @@ __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_c
 // SPLIT: the projection runs on the bf16 matrix pipeline (six bf16 MFMAs per fp32 product, see mbvae_split8): the
 // lane's W12 slice is split once into three bf16 planes (96 registers instead of 64), the E rows are split in
 // registers right before their products, one split per 16 reduction indices shared by the E1 and the E2 tile.
-template <bool WRITE_E12, bool SPLIT>
+// BF16OUT: P and E1|E2 are stored as bf16 (round to nearest even) - the opt-in reduced-precision storage mode; the
+// softmax statistics and wV are computed from the unrounded fp32 values.
+template <bool WRITE_E12, bool SPLIT, bool BF16OUT = false>
 __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
+  constexpr int OS = BF16OUT ? 2 : 4;              // bytes per stored P / E1|E2 element
   extern __shared__ __align__(16) float ef_kv[];   // K rows [64][256], then V rows [64][256]
   float* Ks = ef_kv;
   float* Vs = ef_kv + 64 * 256;
@@ -134,8 +137,11 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       qv[S] = a.Q[(pnode + i0 + ii) * ldq + c];                                                        \
       asm volatile("" : : : "memory");       /* issue the loads here, do not sink them to their use */ \
     }
-#define EF_ST(ptr_rsrc, val, voff, soff) \
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ptr_rsrc, voff, soff, 2)
+#define EF_ST(ptr_rsrc, val, voff, soff)                                                             \
+    do {                                                                                              \
+      if (BF16OUT) __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(val), ptr_rsrc, voff, (soff) / 2, 2); \
+      else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ptr_rsrc, voff, soff, 2);       \
+    } while (0)
 #define EF_TILE(t, S)                                                                                 \
     if ((t) < T) {                                                                                    \
       const int ii = RTq == 2 ? (t) >> 1 : (t), mt = RTq == 2 ? (t) & 1 : 0;                           \
@@ -183,10 +189,10 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const float* Vp = Vs + (32 * mt + 4 * h) * 256 + c;                                              \
       const int64_t prow = (node + i) * n;                                                             \
       const __amdgpu_buffer_rsrc_t rsP =                                                               \
-          __builtin_amdgcn_make_buffer_rsrc(a.P + prow * 256, 0, n * 256 * 4, 0x00020000);             \
+          __builtin_amdgcn_make_buffer_rsrc((char*)a.P + prow * 256 * OS, 0, n * 256 * OS, 0x00020000); \
       const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(                            \
-          WRITE_E12 ? a.E12 + prow * 512 : a.P, 0, WRITE_E12 ? n * 512 * 4 : 0, 0x00020000);           \
-      const int voffP = (4 * h * 256 + c) * 4, voffE = (4 * h * 512 + c) * 4;                          \
+          WRITE_E12 ? (char*)a.E12 + prow * 512 * OS : (char*)a.P, 0, WRITE_E12 ? n * 512 * OS : 0, 0x00020000); \
+      const int voffP = (4 * h * 256 + c) * OS, voffE = (4 * h * 512 + c) * OS;                        \
       float y[16];                                                                                     \
       if (qi_ok && km32 == 0xffffffffu) {          /* full tile, nothing masked */                     \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
@@ -669,11 +675,11 @@ extern "C" {
 // graph_order: NULL, or a permutation of 0..bs-1 (int32): the order in which the graphs' tasks are handed out (largest
 // first, together with work_counter, gives every workgroup a similar amount of work whatever the batch order).
 // MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.
-int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
-                         const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
-                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
-                         const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
-                         hipStream_t stream) {
+static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                               const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                               float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
+                               const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                               hipStream_t stream, bool bf16out) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -705,7 +711,11 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
   void (*k)(EdgeFusedArgs);
   bool lds_ok;
-  if (split) {
+  if (bf16out) {
+    if (!E12) return MBVAE_EINVAL;                   // bf16 storage is a training-form feature
+    k = edge_fused_fwd_kernel<true, true, true>;
+    lds_ok = MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true, true>));
+  } else if (split) {
     k = E12 ? edge_fused_fwd_kernel<true, true> : edge_fused_fwd_kernel<false, true>;
     lds_ok = E12 ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, true>));
   } else {
@@ -716,6 +726,25 @@ int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, con
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
+}
+
+int mbvae_edge_fused_fwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                         float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
+                         const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                         hipStream_t stream) {
+  return edge_fused_fwd_impl(E, W12, b12, Q, K, V, ldq, ye_add, ye_mul, mask, P, wV, lse, E12, work_counter, node_off,
+                             graph_order, bs, n, de, dx, scale, stream, false);
+}
+
+// Training form with bf16 storage: P [bs,n,n,dx] and E12 [bs,n,n,2dx] (required) are written as bf16, everything else
+// as above (static task order, no packed rows).
+int mbvae_edge_fused_fwd_bf16(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                              const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
+                              uint16_t* P, float* wV, float* lse, uint16_t* E12, int64_t bs, int64_t n, int64_t de,
+                              int64_t dx, float scale, hipStream_t stream) {
+  return edge_fused_fwd_impl(E, W12, b12, Q, K, V, ldq, ye_add, ye_mul, mask, (float*)P, wV, lse, (float*)E12, nullptr,
+                             nullptr, nullptr, bs, n, de, dx, scale, stream, true);
 }
 
 // out [M,64] = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta with x [M,64], W1 [128,64], W2 [64,128]

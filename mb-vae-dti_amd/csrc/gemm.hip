@@ -45,6 +45,8 @@ struct GemmArgs {
   int k_per_split; float* partial; float* partial_colsum;
   // optional addend with C's layout (C = epi(...) + addend): only the wave-autonomous tall-skinny kernel applies it
   const float* addend;
+  // reduced-precision storage: the operand / output is bf16 in memory (only the bf16-pipeline edge kernels honour these)
+  int a_bf16, b_bf16, c_bf16;
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col, float keep_row) {
@@ -465,8 +467,15 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 // makes the MFMA B-operand fetch - lane (n, h) reads the 8 consecutive reduction indices of its octet, one
 // ds_read_b128 per plane - conflict-free); the A rows are split in registers right before their MFMAs, one split per
 // 16 reduction indices, shared by the task's TN column tiles.  6 bytes of LDS per weight: K * N <= 25600.
-template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, bool SPLIT = false>
+// SPLIT == 2 (the 32768-weight shapes, whose planes would not fit): the weights stay fp32 in LDS and each lane splits
+// its B octets as well, right after reading them - more vector work per MFMA, still ahead of the fp32 MFMA.
+// ABF / CBF: A is read / C is written as bf16 (the opt-in bf16 storage of the large edge activations).  A bf16 operand
+// IS its own hi plane, so its products need three MFMAs instead of six.
+template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
+  static_assert(!(ABF && (GATE || SPLIT == 0)), "a bf16 A operand runs on the bf16 pipeline and has no gate");
+  constexpr int NP = ABF ? 4 : 8;                  // 16-byte words of A per lane and 64-wide reduction group
+  constexpr unsigned CS = CBF ? 2u : 4u;           // bytes per output element
   constexpr int NT = 64 * WAVES;
   const int N = g.N, LDB = N + 1;
   extern __shared__ __align__(16) float ts2_smem[];
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   const int K = g.K;
   const int LDK = K + 8;                           // SPLIT: bf16 elements per weight column
   unsigned short* Bp = reinterpret_cast<unsigned short*>(ts2_smem);   // SPLIT: [3][N][LDK]
-  if (SPLIT) {
+  if (SPLIT == 1) {
     for (int e = tid; e < N * K; e += NT) {
       int n, k;
       float w;
@@ -528,8 +537,8 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   // accumulators START at the bias, row-mask / ReLU code runs only when needed, and the stores are buffer stores
   // whose row/column offset sits in a scalar register (no per-element address arithmetic).
   const __amdgpu_buffer_rsrc_t rsrcC =
-      __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * 4), 0x00020000);
-  const int voffC = (int)((4u * h * ldc + r) * 4u);      // byte offset of (row 4h, column r) inside a task's tile
+      __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * CS), 0x00020000);
+  const int voffC = (int)((4u * h * ldc + r) * CS);      // byte offset of (row 4h, column r) inside a task's tile
 
 #define TS2_TASK(qq, lt, gi, tile, cb)                                                                \
     const int lt = (qq) / gpt, gi = (qq) - lt * gpt;                                                   \
@@ -539,10 +548,11 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   {                                                                                                   \
     TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
     const int64_t row = (int64_t)tile * 32 + r;                                                        \
-    const float* src = g.A + row * g.lda + gi * 64 + 32 * h;                                           \
+    const float* src = ABF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.A) + row * g.lda + gi * 64 + 32 * h) \
+                           : g.A + row * g.lda + gi * 64 + 32 * h;                                     \
     mbvae_row_mask_bytes(g.mask, mask_mode, row, g.n_nodes, g.A, ma[S], mb[S]);                        \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) bjr[S][j] = biasp[g.bias ? cb * (32 * TN) + j * 32 + r : 0]; \
-    _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[S][p] = *reinterpret_cast<const float4*>(src + 4 * p); \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) ra[S][p] = *reinterpret_cast<const float4*>(src + 4 * p); \
     if (GATE) {                                                                                        \
       const float* gs = g.a_gate + row * g.lda + gi * 64 + 32 * h;                                     \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) rg[S][p] = *reinterpret_cast<const float4*>(gs + 4 * p); \
@@ -558,8 +568,16 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
     float rk = g.a_mask_mode != MBVAE_MASK_NONE ? keepf[S] * g.a_gate_scale : g.a_gate_scale;          \
     if ((q) >= total) rk = 0.f;                                                                        \
     if (!GATE && __ballot(rk != 1.f) == 0ull) {        /* nothing to apply in this wave: only pin the loads */ \
-      _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                  \
+      _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                 \
         float4 v = ra[S][p];                                                                           \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                    \
+        ra[S][p] = v;                                                                                  \
+      }                                                                                                \
+    } else if (ABF) {                                  /* packed bf16 words: a masked row becomes zeros (no scale) */ \
+      _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                 \
+        float4 v = ra[S][p];                                                                           \
+        v.x = rk != 0.f ? v.x : 0.f; v.y = rk != 0.f ? v.y : 0.f;                                      \
+        v.z = rk != 0.f ? v.z : 0.f; v.w = rk != 0.f ? v.w : 0.f;                                      \
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");                    \
         ra[S][p] = v;                                                                                  \
       }                                                                                                \
@@ -585,13 +603,34 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
     }                                                                                                  \
   }
 #define TS2_MMA(q, S)                                                                                 \
-  if (SPLIT) {                                                                                        \
+  if (SPLIT == 2) {                                                                                   \
+    TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
+    const float* Bg = Bs + (gi * 64 + 32 * h) * LDB + cb * (32 * TN) + r;                              \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+      MbvaeSplit3 a;                                                                                   \
+      if (ABF) a.hi = a.mid = a.lo = __builtin_bit_cast(mbvae_bf16x8, ra[S][c]);                       \
+      else a = mbvae_split8(ra[S][(2 * c) % NP].x, ra[S][(2 * c) % NP].y, ra[S][(2 * c) % NP].z, ra[S][(2 * c) % NP].w, \
+                            ra[S][(2 * c + 1) % NP].x, ra[S][(2 * c + 1) % NP].y, ra[S][(2 * c + 1) % NP].z, ra[S][(2 * c + 1) % NP].w); \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+        const float* bp = Bg + 8 * c * LDB + j * 32;                                                   \
+        const MbvaeSplit3 b = mbvae_split8(bp[0], bp[LDB], bp[2 * LDB], bp[3 * LDB], bp[4 * LDB], bp[5 * LDB], bp[6 * LDB], bp[7 * LDB]); \
+        if (!ABF) acc[j] = MBVAE_MFMA_BF16(a.lo, b.hi, acc[j]);                                        \
+        acc[j] = MBVAE_MFMA_BF16(a.hi, b.lo, acc[j]);                                                  \
+        if (!ABF) acc[j] = MBVAE_MFMA_BF16(a.mid, b.mid, acc[j]);                                      \
+        if (!ABF) acc[j] = MBVAE_MFMA_BF16(a.mid, b.hi, acc[j]);                                       \
+        acc[j] = MBVAE_MFMA_BF16(a.hi, b.mid, acc[j]);                                                 \
+        acc[j] = MBVAE_MFMA_BF16(a.hi, b.hi, acc[j]);                                                  \
+      }                                                                                                \
+    }                                                                                                  \
+  } else if (SPLIT == 1) {                                                                            \
     TS2_TASK(min((q), total - 1), lt, gi, tile, cb)                                                    \
     const unsigned short* Bg = Bp + (cb * (32 * TN) + r) * LDK + gi * 64 + 32 * h;                     \
     const int plane = N * LDK;                                                                         \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {          /* 16 reduction indices per step: octet c of each half */ \
-      const MbvaeSplit3 a = mbvae_split8(ra[S][2 * c].x, ra[S][2 * c].y, ra[S][2 * c].z, ra[S][2 * c].w,   \
-                                         ra[S][2 * c + 1].x, ra[S][2 * c + 1].y, ra[S][2 * c + 1].z, ra[S][2 * c + 1].w); \
+      MbvaeSplit3 a;                                                                                   \
+      if (ABF) a.hi = a.mid = a.lo = __builtin_bit_cast(mbvae_bf16x8, ra[S][c]);                       \
+      else a = mbvae_split8(ra[S][(2 * c) % NP].x, ra[S][(2 * c) % NP].y, ra[S][(2 * c) % NP].z, ra[S][(2 * c) % NP].w, \
+                            ra[S][(2 * c + 1) % NP].x, ra[S][(2 * c + 1) % NP].y, ra[S][(2 * c + 1) % NP].z, ra[S][(2 * c + 1) % NP].w); \
       mbvae_bf16x8 bh[TN], bm[TN], bl[TN];                                                             \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
         const unsigned short* bp = Bg + j * 32 * LDK + 8 * c;                                          \
@@ -599,10 +638,10 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
         bm[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + plane);                                    \
         bl[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + 2 * plane);                                \
       }                                                                                                \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.lo, bh[j], acc[j]);    \
+      if (!ABF) { _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.lo, bh[j], acc[j]); }  \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bl[j], acc[j]);    \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bm[j], acc[j]);   \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bh[j], acc[j]);   \
+      if (!ABF) { _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bm[j], acc[j]); } \
+      if (!ABF) { _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.mid, bh[j], acc[j]); } \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bm[j], acc[j]);    \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = MBVAE_MFMA_BF16(a.hi, bh[j], acc[j]);    \
     }                                                                                                  \
@@ -623,15 +662,18 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
 #define TS2_AUX 2   /* non-temporal: the output is not read again by this kernel and must not displace the A rows */
 #endif
 #define TS2_ST(val, rr, j, sbase)                                                                     \
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrcC, voffC,                           \
-                                          (int)((sbase) + ((unsigned)(rr) * ldc + (j) * 32) * 4u), TS2_AUX)
+    do {                                                                                              \
+      const int so_ = (int)((sbase) + ((unsigned)(rr) * ldc + (j) * 32) * CS);                         \
+      if (CBF) __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(val), rsrcC, voffC, so_, TS2_AUX);     \
+      else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrcC, voffC, so_, TS2_AUX);    \
+    } while (0)
 #define TS2_EPI(q, S)                                                                                 \
   {                                                                                                   \
     TS2_TASK((q), lt, gi, tile, cb)                                                                    \
     if ((q) < total && gi == gpt - 1) {                                                                \
       const unsigned long long kb = g.c_mask_mode == MBVAE_MASK_NONE ? ~0ull : __ballot(keepf[S] != 0.f); \
       const unsigned kh = (unsigned)(kb >> (4 * h));   /* bit i: row 4h+i of the tile survives */      \
-      const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * 4u;   /* wave-uniform byte offset */ \
+      const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * CS;   /* wave-uniform byte offset */ \
       float bn[TN];                                                                                    \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = bjr[1 - S][j] * has_bias;                 \
       if (ADD) {                                       /* all addend loads first, then one wait */     \
@@ -709,28 +751,43 @@ static int ts_num_cus() { return mbvae_num_cus(); }
 template <bool B_KC>
 static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   if (mbvae_opt(MBVAE_OPT_NO_TSGEMM)) return MBVAE_EUNSUPPORTED;
-  const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & 3) == 0;
+  const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & (g.a_bf16 ? 7 : 3)) == 0;
+  const bool bf16 = g.a_bf16 || g.c_bf16;
+  if (g.b_bf16 || (bf16 && (g.a_gate || g.act || g.drop_p > 0.f || g.bias && g.c_bf16 || g.a_gate_scale != 1.f)))
+    return MBVAE_EUNSUPPORTED;
   if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
-  if (!mbvae_opt(MBVAE_OPT_NO_TSGEMM2) && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
+  if ((bf16 || !mbvae_opt(MBVAE_OPT_NO_TSGEMM2)) && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
       !(g.addend && g.drop_p > 0.f) && (int64_t)g.M * g.ldc < 0x3fffffff) {
     const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
     // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
     const bool wide = g.N % 128 == 0 && !g.a_gate && !g.addend;
     const int waves = 8;
-    // bf16-pipeline variant where the three weight planes fit in LDS
-    const size_t smem3 = 2 * 3 * (size_t)g.N * (g.K + 8);
-    const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && smem3 <= MBVAE_LDS_LIMIT;
-    const size_t smem2 = split ? smem3 : sizeof(float) * (size_t)g.K * (g.N + 1);
+    // bf16-pipeline variants: weight planes pre-split in LDS where they fit, else split by the lanes as they are read
+    const size_t smem3 = 2 * 3 * (size_t)g.N * (g.K + 8), smemf = sizeof(float) * (size_t)g.K * (g.N + 1);
+    const bool split = bf16 || !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+    const bool split1 = split && smem3 <= MBVAE_LDS_LIMIT, split2 = split && !split1;
+    const size_t smem2 = split1 ? smem3 : smemf;
     void (*k)(GemmArgs) = nullptr;
     bool lds_ok = false;
 #define TS2_PICK(cond, ...)                                                                                         \
     if (k == nullptr && (cond)) { k = __VA_ARGS__; lds_ok = MBVAE_ALLOW_BIG_LDS((__VA_ARGS__)); }
-    TS2_PICK(split && wide, tsgemm2_kernel<4, B_KC, false, 8, false, true>)
-    TS2_PICK(split && g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true, true>)
-    TS2_PICK(split && g.addend, tsgemm2_kernel<2, B_KC, false, 8, true, true>)
-    TS2_PICK(split && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, false, true>)
-    TS2_PICK(split, tsgemm2_kernel<2, B_KC, false, 8, false, true>)
+    if (bf16) {                                    // bf16 storage: the shapes of the edge block's large activations
+      const bool ab = g.a_bf16 != 0, cb = g.c_bf16 != 0;
+      TS2_PICK(ab && !cb && split2 && g.addend, tsgemm2_kernel<2, B_KC, false, 8, true, 2, true, false>)
+      TS2_PICK(ab && !cb && split2 && !g.addend, tsgemm2_kernel<2, B_KC, false, 8, false, 2, true, false>)
+      TS2_PICK(ab && !cb && split1 && !g.addend, tsgemm2_kernel<2, B_KC, false, 8, false, 1, true, false>)
+      TS2_PICK(!ab && cb && split1 && wide, tsgemm2_kernel<4, B_KC, false, 8, false, 1, false, true>)
+      if (k == nullptr) return MBVAE_EUNSUPPORTED;
+    }
+    TS2_PICK(split1 && wide, tsgemm2_kernel<4, B_KC, false, 8, false, 1>)
+    TS2_PICK(split1 && g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true, 1>)
+    TS2_PICK(split1 && g.addend, tsgemm2_kernel<2, B_KC, false, 8, true, 1>)
+    TS2_PICK(split1 && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, false, 1>)
+    TS2_PICK(split1, tsgemm2_kernel<2, B_KC, false, 8, false, 1>)
+    TS2_PICK(split2 && wide, tsgemm2_kernel<4, B_KC, false, 8, false, 2>)
+    TS2_PICK(split2 && g.addend && !g.a_gate, tsgemm2_kernel<2, B_KC, false, 8, true, 2>)
+    TS2_PICK(split2 && !g.addend && !g.a_gate, tsgemm2_kernel<2, B_KC, false, 8, false, 2>)
     TS2_PICK(wide, tsgemm2_kernel<4, B_KC, false, 8>)
     TS2_PICK(g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true>)
     TS2_PICK(g.addend, tsgemm2_kernel<2, B_KC, false, 8, true>)
@@ -741,7 +798,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
     return mbvae_launch_status();
   }
-  if (g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  if (bf16 || g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && mbvae_opt(MBVAE_OPT_TSGEMM_N64))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
@@ -1045,8 +1102,12 @@ __global__ __launch_bounds__(512) void tswgrad2_kernel(GemmArgs g, int nchunks) 
 // segments per half-wave), which ARE the operand octets of the even / odd column tiles once split - no transposition,
 // no LDS, no barrier.  A wave owns one 64 x 64 block of dW; outputs with fewer than eight blocks let the spare waves
 // take every RS-th 16-row group, each (workgroup, row split) writing its own partial for the fixed-order reduction.
-template <int P, int Q, bool GATE>
+// ABF / BBF: dY / X is bf16 in memory (opt-in bf16 storage of the large edge activations): a lane's 4-byte load then
+// holds its two columns, the octets are assembled with byte permutes, and a bf16 operand - being its own hi plane -
+// drops the product terms of its (zero) mid and lo planes.
+template <int P, int Q, bool GATE, bool ABF = false, bool BBF = false>
 __global__ __launch_bounds__(512) void tswgrad3_kernel(GemmArgs g, int nchunks) {
+  static_assert(!(ABF && GATE), "no gate on a bf16 operand");
   constexpr int NBQ = Q / 64, NBLK = (P / 64) * NBQ, RS = 8 / NBLK, GPC = 4;
   static_assert(P % 64 == 0 && Q % 64 == 0 && NBLK >= 1 && NBLK <= 8 && RS * NBLK == 8, "1, 2, 4 or 8 blocks of 64 x 64");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1078,9 +1139,11 @@ __global__ __launch_bounds__(512) void tswgrad3_kernel(GemmArgs g, int nchunks) 
     const int64_t row = c0 + (gq % GPC) * 16;                                                          \
     mbvae_row_mask_bytes(g.mask, g.a_mask_mode, c0 + lane, g.n_nodes, g.A, ma[S], mb[S]);              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                    \
-      ra[S][i] = *reinterpret_cast<const float2*>(g.A + (row + i) * g.lda + offA);                     \
+      if (ABF) ra[S][i].x = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.A) + (row + i) * g.lda + offA); \
+      else ra[S][i] = *reinterpret_cast<const float2*>(g.A + (row + i) * g.lda + offA);                \
       if (GATE) rg[S][i] = *reinterpret_cast<const float2*>(g.a_gate + (row + i) * g.lda + offA);      \
-      rb[S][i] = *reinterpret_cast<const float2*>(g.B + (row + i) * g.ldb + offB);                     \
+      if (BBF) rb[S][i].x = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.B) + (row + i) * g.ldb + offB); \
+      else rb[S][i] = *reinterpret_cast<const float2*>(g.B + (row + i) * g.ldb + offB);                \
     }                                                                                                  \
     asm volatile("" : : : "memory");                                                                   \
   }
@@ -1090,42 +1153,60 @@ __global__ __launch_bounds__(512) void tswgrad3_kernel(GemmArgs g, int nchunks) 
     asm volatile("v_mov_b32 %0, 0" : "=v"(late) : : "memory");                                         \
     const unsigned long long kb = __ballot(mbvae_mask_keep(g.a_mask_mode, ma[S] | late, mb[S] | late)); \
     const float sc = (q) < total ? g.a_gate_scale : 0.f;                                               \
-    if (!GATE && kb == ~0ull && sc == 1.f) {           /* nothing to apply: only pin the loads, sum columns */ \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
-        float2 v = ra[S][i];                                                                           \
-        float2 b = rb[S][i];                                                                           \
-        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
-        cs0 += v.x; cs1 += v.y;                                                                        \
-        ra[S][i] = v; rb[S][i] = b;                                                                    \
-      }                                                                                                \
-    } else {                                                                                           \
-      const unsigned kbits = (unsigned)(kb >> ((W3_GROUP(q) % GPC) * 16 + 8 * h));   /* bit i: row 8h + i */ \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
-        float2 v = ra[S][i];                                                                           \
-        float2 b = rb[S][i];                                                                           \
-        if (GATE) {                                                                                    \
-          if (!(rg[S][i].x > 0.f)) v.x = 0.f;                                                          \
-          if (!(rg[S][i].y > 0.f)) v.y = 0.f;                                                          \
+    const bool plain = !GATE && kb == ~0ull && sc == 1.f;   /* nothing to apply: only pin the loads, sum columns */ \
+    const unsigned kbits = (unsigned)(kb >> ((W3_GROUP(q) % GPC) * 16 + 8 * h));   /* bit i: row 8h + i */ \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                    \
+      float2 v = ra[S][i];                                                                             \
+      float2 b = rb[S][i];                                                                             \
+      if (ABF) {                                                                                       \
+        if (!plain) v.x = (((kbits >> i) & 1u) && sc != 0.f) ? v.x : 0.f;    /* both columns' bits at once */ \
+        asm volatile("" : "+v"(v.x), "+v"(b.x) : : "memory");                                          \
+        if (!BBF) asm volatile("" : "+v"(b.y) : : "memory");                                           \
+        cs0 += __uint_as_float(__float_as_uint(v.x) << 16); cs1 += __uint_as_float(__float_as_uint(v.x) & 0xffff0000u); \
+      } else {                                                                                         \
+        if (!plain) {                                                                                  \
+          if (GATE) {                                                                                  \
+            if (!(rg[S][i].x > 0.f)) v.x = 0.f;                                                        \
+            if (!(rg[S][i].y > 0.f)) v.y = 0.f;                                                        \
+          }                                                                                            \
+          const float rk = ((kbits >> i) & 1u) ? sc : 0.f;                                             \
+          v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                          \
         }                                                                                              \
-        const float rk = ((kbits >> i) & 1u) ? sc : 0.f;                                               \
-        v.x = rk != 0.f ? v.x * rk : 0.f; v.y = rk != 0.f ? v.y * rk : 0.f;                            \
-        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x), "+v"(b.y) : : "memory");                    \
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(b.x) : : "memory");                               \
+        if (!BBF) asm volatile("" : "+v"(b.y) : : "memory");                                           \
         cs0 += v.x; cs1 += v.y;                                                                        \
-        ra[S][i] = v; rb[S][i] = b;                                                                    \
       }                                                                                                \
+      ra[S][i] = v; rb[S][i] = b;                                                                      \
     }                                                                                                  \
   }
   // smallest terms first; the four tiles alternate so that consecutive MFMAs never wait on each other's accumulator
-#define W3_TERM(pa, pb)                                                                               \
-    acc[0][0] = MBVAE_MFMA_BF16(a0.pa, b0.pb, acc[0][0]); acc[0][1] = MBVAE_MFMA_BF16(a0.pa, b1.pb, acc[0][1]); \
-    acc[1][0] = MBVAE_MFMA_BF16(a1.pa, b0.pb, acc[1][0]); acc[1][1] = MBVAE_MFMA_BF16(a1.pa, b1.pb, acc[1][1]);
+#define W3_TERM(pa, pb, AH, BH)                                                                       \
+    if ((AH || !ABF) && (BH || !BBF)) {                                                                \
+      acc[0][0] = MBVAE_MFMA_BF16(a0.pa, b0.pb, acc[0][0]); acc[0][1] = MBVAE_MFMA_BF16(a0.pa, b1.pb, acc[0][1]); \
+      acc[1][0] = MBVAE_MFMA_BF16(a1.pa, b0.pb, acc[1][0]); acc[1][1] = MBVAE_MFMA_BF16(a1.pa, b1.pb, acc[1][1]); \
+    }
+  // a lane's eight rows of one operand -> the split planes of its even (x0) and odd (x1) column
+#define W3_OPERAND(BF, rr, x0, x1)                                                                    \
+    MbvaeSplit3 x0, x1;                                                                                \
+    if (BF) {                                                                                          \
+      mbvae_u32x4 e_, o_;                                                                              \
+      _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                  \
+        const unsigned w0 = __float_as_uint(rr[2 * p].x), w1 = __float_as_uint(rr[2 * p + 1].x);       \
+        e_[p] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);   /* low halves: the even column's rows 2p, 2p+1 */ \
+        o_[p] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);   /* high halves: the odd column's */        \
+      }                                                                                                \
+      x0.hi = x0.mid = x0.lo = __builtin_bit_cast(mbvae_bf16x8, e_);                                   \
+      x1.hi = x1.mid = x1.lo = __builtin_bit_cast(mbvae_bf16x8, o_);                                   \
+    } else {                                                                                           \
+      x0 = mbvae_split8(rr[0].x, rr[1].x, rr[2].x, rr[3].x, rr[4].x, rr[5].x, rr[6].x, rr[7].x);       \
+      x1 = mbvae_split8(rr[0].y, rr[1].y, rr[2].y, rr[3].y, rr[4].y, rr[5].y, rr[6].y, rr[7].y);       \
+    }
 #define W3_MMA(S)                                                                                     \
   {                                                                                                   \
-    const MbvaeSplit3 a0 = mbvae_split8(ra[S][0].x, ra[S][1].x, ra[S][2].x, ra[S][3].x, ra[S][4].x, ra[S][5].x, ra[S][6].x, ra[S][7].x); \
-    const MbvaeSplit3 a1 = mbvae_split8(ra[S][0].y, ra[S][1].y, ra[S][2].y, ra[S][3].y, ra[S][4].y, ra[S][5].y, ra[S][6].y, ra[S][7].y); \
-    const MbvaeSplit3 b0 = mbvae_split8(rb[S][0].x, rb[S][1].x, rb[S][2].x, rb[S][3].x, rb[S][4].x, rb[S][5].x, rb[S][6].x, rb[S][7].x); \
-    const MbvaeSplit3 b1 = mbvae_split8(rb[S][0].y, rb[S][1].y, rb[S][2].y, rb[S][3].y, rb[S][4].y, rb[S][5].y, rb[S][6].y, rb[S][7].y); \
-    W3_TERM(lo, hi) W3_TERM(hi, lo) W3_TERM(mid, mid) W3_TERM(mid, hi) W3_TERM(hi, mid) W3_TERM(hi, hi)  \
+    W3_OPERAND(ABF, ra[S], a0, a1)                                                                     \
+    W3_OPERAND(BBF, rb[S], b0, b1)                                                                     \
+    W3_TERM(lo, hi, false, true) W3_TERM(hi, lo, true, false) W3_TERM(mid, mid, false, false)          \
+    W3_TERM(mid, hi, false, true) W3_TERM(hi, mid, true, false) W3_TERM(hi, hi, true, true)            \
   }
 
   if (total > 0) {
@@ -1148,6 +1229,7 @@ __global__ __launch_bounds__(512) void tswgrad3_kernel(GemmArgs g, int nchunks) 
 #undef W3_FETCH
 #undef W3_PREP
 #undef W3_TERM
+#undef W3_OPERAND
 #undef W3_MMA
 
   // ---- partial dW of this (workgroup, row split): tile (i, j) holds rows 64 wm + 2 m + i, columns 64 wn + 2 c + j
@@ -1209,7 +1291,7 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
   if (!aligned || R < 32768 || R % 32 || P * Q > 32768 || g.bias || g.act || g.drop_p > 0.f || g.c_mask_mode != MBVAE_MASK_NONE)
     return MBVAE_EUNSUPPORTED;
   // every edge-path shape: the bf16-pipeline kernel (one 64 x 64 block of dW per wave)
-  if (!mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P % 64 == 0 && Q % 64 == 0 &&
+  if ((g.a_bf16 || g.b_bf16 || !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA)) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P % 64 == 0 && Q % 64 == 0 &&
       (int64_t)8 * g.lda + P < 0x7fffffff && (int64_t)8 * g.ldb + Q < 0x7fffffff && workspace != nullptr) {
     const int nblk = (P / 64) * (Q / 64);
     if (nblk == 1 || nblk == 2 || nblk == 4 || nblk == 8) {
@@ -1222,8 +1304,13 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
         const bool gate3 = g.a_gate != nullptr;
         void (*k3)(GemmArgs, int) = nullptr;
 #define TW3_PICK(p, q) if (P == p && Q == q) k3 = gate3 ? tswgrad3_kernel<p, q, true> : tswgrad3_kernel<p, q, false>;
-        TW3_PICK(512, 64) TW3_PICK(256, 64) TW3_PICK(64, 256) TW3_PICK(128, 64) TW3_PICK(64, 128) TW3_PICK(128, 128) TW3_PICK(64, 64)
-        TW3_PICK(64, 512) TW3_PICK(256, 128) TW3_PICK(128, 256)
+        if (g.a_bf16 || g.b_bf16) {                // bf16 storage: the edge block's two large-activation gradients
+          if (!gate3 && g.a_gate_scale == 1.f && g.a_bf16 && !g.b_bf16 && P == 512 && Q == 64) k3 = tswgrad3_kernel<512, 64, false, true, false>;
+          if (!gate3 && !g.a_bf16 && g.b_bf16 && P == 64 && Q == 256) k3 = tswgrad3_kernel<64, 256, false, false, true>;
+        } else {
+          TW3_PICK(512, 64) TW3_PICK(256, 64) TW3_PICK(64, 256) TW3_PICK(128, 64) TW3_PICK(64, 128) TW3_PICK(128, 128) TW3_PICK(64, 64)
+          TW3_PICK(64, 512) TW3_PICK(256, 128) TW3_PICK(128, 256)
+        }
 #undef TW3_PICK
         if (k3 != nullptr) {
           hipLaunchKernelGGL(k3, dim3(grid3), dim3(512), 0, stream, g, nchunks3);
@@ -1234,6 +1321,7 @@ static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_
       }
     }
   }
+  if (g.a_bf16 || g.b_bf16) return MBVAE_EUNSUPPORTED;   // bf16 storage exists for the kernel above only
   if (P * Q > 16384 && !(P == 512 && Q == 64 && !g.a_gate)) return MBVAE_EUNSUPPORTED;
   // the widest edge-path gradient (fused e_mul|e_add projection, 512 x 64) runs on the LDS-free kernel: 8 % faster there
   if (!mbvae_opt(MBVAE_OPT_NO_TSWGRAD2) && R % 64 == 0 && (g.lda & 1) == 0 && (g.ldb & 1) == 0 && P == 512 && Q == 64 && !g.a_gate &&
@@ -1445,6 +1533,7 @@ template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
   if (!g.A || !g.B || !g.C) return MBVAE_EINVAL;
+  const bool bf16 = g.a_bf16 || g.b_bf16 || g.c_bf16;
   if (A_KC) {
     const int st = tsgemm_try<B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
@@ -1453,6 +1542,7 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
     const int st = tswgrad_try(g, workspace, ws_bytes, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
   }
+  if (bf16) return MBVAE_EUNSUPPORTED;             // only the edge-path kernels read or write bf16 storage
   {
     const int st = smallm_try<A_KC, B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
@@ -1593,6 +1683,57 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
   g.lda = lddy; g.ldb = ldx; g.ldc = K;
   g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
   g.accumulate = accumulate; g.colsum = db;
+  return gemm_dispatch<false, false>(g, workspace, ws_bytes, stream);
+}
+
+// ---- bf16 storage of the edge block's large activations (opt-in; fp32 weights, fp32 accumulation) ----------------
+// y[M,N] (fp32) = rowmask(x[M,K] (bf16) @ w[N,K]^T + bias).  Edge-path shapes only (M >= 32768, M % 32 == 0,
+// K % 64 == 0, N % 64 == 0, K*N <= 32768), MBVAE_EUNSUPPORTED otherwise.
+int mbvae_linear_fwd_bf16(const uint16_t* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                          int64_t M, int64_t K, int64_t N, const uint8_t* mask, int mask_mode, int n_nodes,
+                          hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  GemmArgs g = {};
+  g.A = (const float*)x; g.B = w; g.C = y; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.lda = ldx; g.ldb = K; g.ldc = ldy;
+  g.a_gate_scale = 1.f; g.mask = mask; g.c_mask_mode = mask_mode; g.n_nodes = n_nodes; g.bias = bias;
+  g.a_bf16 = 1;
+  return gemm_dispatch<true, true>(g, nullptr, 0, stream);
+}
+
+// dx[M,K] = rowmask(dy)[M,N] @ w[N,K] (+ addend[M,K], fp32, may be NULL).  dy_bf16 / dx_bf16 say which of the two
+// activations is bf16 in memory (exactly one of them; the other is fp32).  Edge-path shapes only.
+int mbvae_linear_bwd_input_bf16(const void* dy, int dy_bf16, int64_t lddy, const float* w, const float* addend, void* dx,
+                                int dx_bf16, int64_t lddx, int64_t M, int64_t K, int64_t N, const uint8_t* mask,
+                                int mask_mode, int n_nodes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if ((dy_bf16 != 0) == (dx_bf16 != 0) || (addend && dx_bf16)) return MBVAE_EUNSUPPORTED;
+  GemmArgs g = {};
+  g.A = (const float*)dy; g.B = w; g.C = (float*)dx; g.M = (int)M; g.N = (int)K; g.K = (int)N;
+  g.lda = lddy; g.ldb = K; g.ldc = lddx;
+  g.a_gate_scale = 1.f; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.addend = addend; g.a_bf16 = dy_bf16 != 0; g.c_bf16 = dx_bf16 != 0;
+  return gemm_dispatch<true, false>(g, nullptr, 0, stream);
+}
+
+// dw[N,K] = rowmask(dy)[M,N]^T @ x[M,K];  db[N] = column sums of rowmask(dy) (may be NULL).  dy_bf16 / x_bf16: which
+// operand is bf16 in memory (exactly one).  Shapes: (N, K) = (512, 64) with dy bf16, (64, 256) with x bf16.
+int mbvae_linear_bwd_weight_bf16(const void* dy, int dy_bf16, int64_t lddy, const void* x, int x_bf16, int64_t ldx,
+                                 float* dw, float* db, int64_t M, int64_t K, int64_t N, const uint8_t* mask,
+                                 int mask_mode, int n_nodes, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if ((dy_bf16 != 0) == (x_bf16 != 0)) return MBVAE_EUNSUPPORTED;
+  GemmArgs g = {};
+  g.A = (const float*)dy; g.B = (const float*)x; g.C = dw; g.M = (int)N; g.N = (int)K; g.K = (int)M;
+  g.lda = lddy; g.ldb = ldx; g.ldc = K;
+  g.a_gate_scale = 1.f; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes; g.colsum = db;
+  g.a_bf16 = dy_bf16 != 0; g.b_bf16 = x_bf16 != 0;
   return gemm_dispatch<false, false>(g, workspace, ws_bytes, stream);
 }
 

@@ -19,12 +19,17 @@ SIGNATURES = {
     "mbvae_get_option": [c_char_p],
     "mbvae_linear_fwd": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P, _I, _I, _F, _U, _I, _P, _L, _P],
     "mbvae_linear_bwd_input": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
+    "mbvae_linear_fwd_bf16": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _I, _I, _P],
+    "mbvae_linear_bwd_input_bf16": [_P, _I, _L, _P, _P, _P, _I, _L, _L, _L, _L, _P, _I, _I, _P],
+    "mbvae_linear_bwd_weight_bf16": [_P, _I, _L, _P, _I, _L, _P, _P, _L, _L, _L, _P, _I, _I, _P, _L, _P],
     "mbvae_linear_bwd_input_add": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _P],
     "mbvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
     "mbvae_edge_attn_fwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 6 + [_L, _L, _L, _F, _P],
     "mbvae_edge_attn_bwd_workspace": [_L, _L, _L],
     "mbvae_edge_attn_bwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P, _L, _P],
     "mbvae_edge_fused_fwd": [_P] * 6 + [_L] + [_P] * 10 + [_L, _L, _L, _L, _F, _P],
+    "mbvae_edge_attn_bwd_bf16": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P, _L, _P],
+    "mbvae_edge_fused_fwd_bf16": [_P] * 6 + [_L] + [_P] * 7 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_ffn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],
     "mbvae_ln_residual_fwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P],

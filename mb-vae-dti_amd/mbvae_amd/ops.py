@@ -4,12 +4,28 @@ Every function here requires CUDA(HIP) float32 tensors and calls libmbvae_hip.so
 falls back to eager PyTorch arithmetic.
 """
 import math
+import os
 
 import torch
 
 from . import _lib
 
 MASK_NONE, MASK_NODE, MASK_EDGE = 0, 1, 2
+
+# Opt-in reduced-precision STORAGE of the training step's largest activations (the edge block's [bs,n,n,2dx]
+# projection output and its gradient, the attention output P [bs,n,n,dx] and its gradient): bf16 in memory, fp32
+# weights, fp32 arithmetic and accumulation everywhere.  Off by default: the default path is fp32 end to end.
+_BF16_STORAGE = os.environ.get("MBVAE_BF16_STORAGE", "0") not in ("", "0")
+
+
+def set_bf16_storage(on):
+    """Switch the bf16 storage mode of the edge block on or off (takes effect at the next forward)."""
+    global _BF16_STORAGE
+    _BF16_STORAGE = bool(on)
+
+
+def bf16_storage():
+    return _BF16_STORAGE
 
 _ws_cache = {}
 
@@ -66,16 +82,26 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias):
-        x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
+        bf16_in = x.dtype == torch.bfloat16          # bf16 storage mode: the attention output P feeding e_out
+        if bf16_in:
+            if not x.is_cuda or act or drop_p > 0 or with_alias:
+                raise RuntimeError("a bf16 input is only supported for a plain Linear on the GPU (the e_out projection)")
+            x2 = x.contiguous().reshape(-1, x.shape[-1])
+        else:
+            x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
         w = _f32c(w, "weight")
         M, K = x2.shape
         N = w.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         ws = workspace(x.device)
         m8 = _mask_u8(mask)
-        _lib.call("mbvae_linear_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N, act,
-                  _ptr(m8), mask_mode, n_nodes, float(drop_p), int(seed), 0, ws.data_ptr(), ws.numel(), _stream(),
-                  tag=(M, K, N))
+        if bf16_in:
+            _lib.call("mbvae_linear_fwd_bf16", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N,
+                      _ptr(m8), mask_mode, n_nodes, _stream(), tag=(M, K, N))
+        else:
+            _lib.call("mbvae_linear_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N, act,
+                      _ptr(m8), mask_mode, n_nodes, float(drop_p), int(seed), 0, ws.data_ptr(), ws.numel(), _stream(),
+                      tag=(M, K, N))
         gated = act == 1
         ctx.save_for_backward(x2, w, y if gated else None, m8)
         ctx.cfg = (mask_mode, n_nodes, float(drop_p), gated, b is not None, x.shape)
@@ -94,6 +120,21 @@ class _Linear(torch.autograd.Function):
         # a ReLU gate (y > 0) already implies the row mask
         mm = MASK_NONE if gated else mask_mode
         dx = dw = db = None
+        if x2.dtype == torch.bfloat16:               # bf16 storage mode: dx leaves as bf16, x is read as bf16
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
+                _lib.call("mbvae_linear_bwd_input_bf16", dy2.data_ptr(), 0, N, w.data_ptr(), 0, dx.data_ptr(), 1, K, M, K, N,
+                          _ptr(m8), mm, n_nodes, _stream(), tag=(M, K, N))
+                dx = dx.reshape(xshape)
+            need_db = has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1] or need_db:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                db = torch.empty((N,), dtype=torch.float32, device=dy.device) if need_db else None
+                _lib.call("mbvae_linear_bwd_weight_bf16", dy2.data_ptr(), 0, N, x2.data_ptr(), 1, K, dw.data_ptr(), _ptr(db),
+                          M, K, N, _ptr(m8), mm, n_nodes, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+                if not ctx.needs_input_grad[1]:
+                    dw = None
+            return dx, dw, db, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             folded = False
@@ -177,11 +218,16 @@ def _edge_input_grads(E, w, m8, stats, arg, n_nodes, has_bias, dy, dstats, dres,
     ws = workspace(E.device)
     st = _stream()
     dE = dw = db = None
-    dy2 = _f32c(dy, "dy").reshape(M, N) if dy is not None else None
+    bf16 = dy is not None and dy.dtype == torch.bfloat16        # bf16 storage mode: the projection output's gradient
+    dy2 = (dy.contiguous() if bf16 else _f32c(dy, "dy")).reshape(M, N) if dy is not None else None
     if need_dE:
         dE = torch.empty_like(E)
         have = False
-        if dy2 is not None:
+        if bf16:
+            dres = _f32c(dres, "dres") if dres is not None else None
+            _lib.call("mbvae_linear_bwd_input_bf16", dy2.data_ptr(), 1, N, w.data_ptr(), _ptr(dres), dE.data_ptr(), 0, K,
+                      M, K, N, m8.data_ptr(), MASK_EDGE, n_nodes, st, tag=(M, K, N))
+        elif dy2 is not None:
             if dres is not None:
                 dres = _f32c(dres, "dres")
                 have = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dE.data_ptr(),
@@ -202,8 +248,12 @@ def _edge_input_grads(E, w, m8, stats, arg, n_nodes, has_bias, dy, dstats, dres,
     if need_dw and dy2 is not None:
         dw = torch.empty((N, K), dtype=torch.float32, device=E.device)
         db = torch.empty((N,), dtype=torch.float32, device=E.device) if has_bias else None
-        _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
-                  0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+        if bf16:
+            _lib.call("mbvae_linear_bwd_weight_bf16", dy2.data_ptr(), 1, N, x2.data_ptr(), 0, K, dw.data_ptr(), _ptr(db),
+                      M, K, N, m8.data_ptr(), MASK_EDGE, n_nodes, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
+        else:
+            _lib.call("mbvae_linear_bwd_weight", dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), _ptr(db), M, K, N,
+                      0, 1.0, m8.data_ptr(), MASK_EDGE, n_nodes, 0, ws.data_ptr(), ws.numel(), st, tag=(M, K, N))
     return dE, dw, db
 
 
@@ -244,16 +294,24 @@ class _EdgeAttention(torch.autograd.Function):
 
 def _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV):
     bs, n, dx = wV.shape
-    dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=wV.device)
+    bf16 = E12.dtype == torch.bfloat16               # bf16 storage mode: E12, dP and dE12 are bf16 in memory
+    if dP is None:
+        dP = torch.zeros((bs, n, n, dx), dtype=E12.dtype, device=wV.device)
+    elif bf16:
+        dP = dP.to(torch.bfloat16).contiguous()
+    else:
+        dP = _f32c(dP)
     dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
     dE12 = torch.empty_like(E12)
     dQKV = torch.empty_like(QKV)
     dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
     q, e, dq, de = QKV.data_ptr(), E12.data_ptr(), dQKV.data_ptr(), dE12.data_ptr()
+    es = 2 if bf16 else 4                            # bytes per E12 element: e_add's column block starts dx elements in
     ws = workspace(wV.device)
-    _lib.call("mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx, e, e + 4 * dx, 2 * dx,
+    _lib.call("mbvae_edge_attn_bwd_bf16" if bf16 else "mbvae_edge_attn_bwd", q, q + 4 * dx, q + 8 * dx, 3 * dx,
+              e, e + es * dx, 2 * dx,
               ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
-              de, de + 4 * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, scale,
+              de, de + es * dx, dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, dx, scale,
               ws.data_ptr(), ws.numel(), _stream())
     return dQKV, dE12, dya, dym
 
@@ -284,19 +342,27 @@ class _EdgeBlock(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:6])
         if pack is not None and (need_grad or order is None or not order.sparse):
             raise RuntimeError("packed node rows are an inference-only layout (sparse row order, no gradients)")
-        P = torch.empty((bs, n, n, dx), dtype=torch.float32, device=dev)
+        # bf16 storage mode: P and E1|E2 leave the fused kernel as bf16 (training form, fused shapes only)
+        store = torch.bfloat16 if (_BF16_STORAGE and need_grad and de == 64 and dx == 256 and n <= 64) else torch.float32
+        P = torch.empty((bs, n, n, dx), dtype=store, device=dev)
         if pack is None:
             wV = torch.empty((bs, n, dx), dtype=torch.float32, device=dev)
         else:                           # packed rows; the padding row is never written by the kernel and must be finite
             wV = torch.zeros((QKV.shape[0], dx), dtype=torch.float32, device=dev)
         lse = torch.empty_like(wV)
-        E12 = torch.empty((bs, n, n, N), dtype=torch.float32, device=dev) if need_grad else None
+        E12 = torch.empty((bs, n, n, N), dtype=store, device=dev) if need_grad else None
         q = QKV.data_ptr()
-        fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
-                          ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
-                          _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(),
-                          0 if pack is None else pack.off.data_ptr(), 0 if pack is None else pack.by_size.data_ptr(),
-                          bs, n, de, dx, scale, _stream(), allow_unsupported=True)
+        if store == torch.bfloat16:
+            _lib.call("mbvae_edge_fused_fwd_bf16", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
+                      ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
+                      E12.data_ptr(), bs, n, de, dx, scale, _stream())
+            fused = True
+        else:
+            fused = _lib.call("mbvae_edge_fused_fwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
+                              ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
+                              _ptr(E12), 0 if need_grad else _work_counter(dev).data_ptr(),
+                              0 if pack is None else pack.off.data_ptr(), 0 if pack is None else pack.by_size.data_ptr(),
+                              bs, n, de, dx, scale, _stream(), allow_unsupported=True)
         if not fused and pack is not None:
             raise RuntimeError("packed node rows need the fused attention kernel (de = 64, dx = 256, n <= 64)")
         if not fused:

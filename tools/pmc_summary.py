@@ -54,8 +54,9 @@ def sq_summary(sq_dir, man, marker_grid, tag):
             mf = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
             va = 4.0 * d.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles
             wa = d.get("SQ_WAIT_ANY", 0.0) / max(d.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-            key = f"{name.replace(':E', '')}|{k[:48]}"
-            out[key] = {"mfma_busy_frac": round(mf, 4), "valu_busy_frac": round(va, 4), "wait_any_frac": round(wa, 4)}
+            key = f"{name.replace(':E', '')}|{k[:64]}"
+            out[key] = {"mfma_busy_frac": round(mf, 4), "valu_busy_frac": round(va, 4), "wait_any_frac": round(wa, 4),
+                        "gui_active": d["GRBM_GUI_ACTIVE"]}
             lines.append(f"{name},{k[:60]},{d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{d['GRBM_GUI_ACTIVE']:.0f},{mf:.4f},{va:.4f},{wa:.4f}")
     json.dump(out, open("profiles/mfma_busy_by_entry.json", "w"), indent=1)
     open(f"profiles/{tag}_mfma_busy_by_entry.csv", "w").write("\n".join(lines) + "\n")
