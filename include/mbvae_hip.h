@@ -229,6 +229,22 @@ int mbvae_reverse_sample(const float* logitsX, const float* logitsE, const float
                          int64_t* Ec, float* Xs, float* Es, float* probX, float* probE, int64_t bs, int64_t n,
                          int64_t cx, int64_t ce, mbvae_stream_t stream);
 
+/* ---- fused edge block, training form with the projection recomputed in the backward ------------------------
+ * Same mathematics as mbvae_edge_fused_fwd + mbvae_edge_attn_bwd (graph_transformer.py:206-267 and its autograd
+ * backward); the pair exists to keep E1|E2 [bs,n,n,2dx] out of memory: the forward writes P (for every pair), wV and
+ * lse only, the backward forms E1|E2 again from E on the matrix cores.  de == 64, dx == 256, n <= 64; the forward
+ * returns MBVAE_EUNSUPPORTED for batches of fewer than one graph per two compute units (the backward runs one
+ * workgroup per graph) - use the storing pair then.  Bitwise reproducible. */
+int mbvae_edge_fused_fwd_recompute(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                                   const float* V, int64_t ldq, const float* ye_add, const float* ye_mul,
+                                   const uint8_t* mask, float* P, float* wV, float* lse, int64_t bs, int64_t n,
+                                   int64_t de, int64_t dx, float scale, mbvae_stream_t stream);
+int mbvae_edge_fused_bwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                         const float* lse, const float* dP, const float* dwV, float* dE12, float* dQ, float* dK,
+                         float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx,
+                         float scale, mbvae_stream_t stream);
+
 /* ---- opt-in bf16 STORAGE of the edge block's large activations ------------------------------------------
  * No counterpart in the reference (which trains in fp32 throughout; its own mixed-precision switch is Lightning's
  * `precision` flag, mb_vae_dti/training/run.py:642).  The projection output E1|E2 [bs,n,n,2dx], the attention output

@@ -38,12 +38,14 @@ enum MbvaeOption {
   MBVAE_OPT_NO_EA_PREFETCH,   // edge-attention backward: do NOT request the next query row's operands a row ahead
   MBVAE_OPT_GEMM_TILE,     // -1: automatic; 0 = 64x64, 1 = 128x64, 2 = 128x128
   MBVAE_OPT_NO_SPLIT_MFMA, // edge-path products on the native fp32 MFMA instead of six bf16 MFMAs of a three-way split
+  MBVAE_OPT_NO_E12_RECOMPUTE,   // training: store the e_mul|e_add projection output in the forward instead of recomputing it in the backward
   MBVAE_OPT_COUNT
 };
 inline const char* const* mbvae_option_names() {
   static const char* const names[MBVAE_OPT_COUNT] = {"NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64", "NO_TSWGRAD", "NO_TSWGRAD2",
                                                      "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
-                                                     "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE", "NO_SPLIT_MFMA"};
+                                                     "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE", "NO_SPLIT_MFMA",
+                                                     "NO_E12_RECOMPUTE"};
   return names;
 }
 struct MbvaeOptions {

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
   const int ntasks = a.bs * a.ichunks;
   const int ipc = (n + a.ichunks - 1) / a.ichunks;   // query rows per task
+  const bool st_e12 = a.E12 != nullptr;            // training form without E1|E2 output: the backward recomputes it
 
   float4 ra[2][8];
   float qv[2];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const float e1 = acc1[v], e2 = acc2[v];                                                      \
-          if (WRITE_E12) {                                                                             \
+          if (WRITE_E12 && st_e12) {                                                                   \
             EF_ST(rsE, e1, voffE, (32 * mt + rr) * 2048);                                              \
             EF_ST(rsE, e2, voffE, (32 * mt + rr) * 2048 + 1024);                                       \
           }                                                                                            \
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           const float kv = in ? Kp[rr * 256] : 0.f;                                                    \
           const float yy = qs * kv * (e1 + 1.f) + e2;                                                  \
           if (in && (WRITE_E12 || pair_ok)) {      /* inference: P of a masked pair is never read */  \
-            if (WRITE_E12) {                                                                           \
+            if (WRITE_E12 && st_e12) {                                                                 \
               EF_ST(rsE, e1, voffE, (32 * mt + rr) * 2048);                                            \
               EF_ST(rsE, e2, voffE, (32 * mt + rr) * 2048 + 1024);                                     \
             }                                                                                          \
@@ -286,6 +287,159 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
 #undef EF_FETCH
 #undef EF_TILE
 #undef EF_ST
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the fused block with the projection RECOMPUTED: E1|E2 = E W12^T + b12 is formed again on the matrix
+// cores from E (64 floats per pair) instead of being read back (512 floats per pair), so the forward does not store
+// it either - 4 GB less HBM traffic per layer at bs = 256, n = 64.  Same tiling as the forward: one workgroup per
+// graph, wave w owns channels [32w, 32w+32) of E1 and E2, a tile is 32 keys x 32 channels of one query row with a
+// lane holding 16 keys of its channel.  The sums follow from that ownership without LDS, atomics or a second kernel:
+//   dK[j], dV[j]   (sum over query rows)  lane-private accumulators of the current KEY tile: the key tiles are the
+//                                         OUTER loop, so 2 x 16 registers suffice and every (key, channel) has one owner
+//   dQ[i]          (sum over keys)        in-tile sum + the other half-wave; the second key tile adds to what the same
+//                                         lane stored for the first one
+//   dye_add/mul    (sum over everything)  lane-private, the two half-waves meet once per graph
+// in a fixed order: bitwise reproducible.  dE1|dE2 [bs,n,n,2dx] is written for the projection's gradient kernels.
+struct EdgeFusedBwdArgs {
+  const float* E; const float* W; const float* bias;
+  const float* Q; const float* K; const float* V; int ldq;
+  const float* ye_mul; const uint8_t* mask; const float* wV; const float* lse;
+  const float* dP; const float* dwV;
+  float* dE12; float* dQ; float* dK; float* dV; float* dye_add; float* dye_mul;
+  int bs, n; float scale;
+};
+
+__global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a) {
+  // Register budget (256 per lane at 512 threads): the lane's W12 slice as three bf16 planes would take 96.  Its hi and
+  // mid planes therefore live in LDS - 16 bytes per (plane, octet, E1/E2, thread), written and read by their owner only,
+  // so no barrier guards them - and only the lo planes stay in registers.  K and V need no LDS here: with the key
+  // tile as the outer loop a lane's 16 keys are fixed for a whole pass over the query rows and sit in registers.
+  extern __shared__ __align__(16) float ef_kv[];
+  mbvae_bf16x8* wl = reinterpret_cast<mbvae_bf16x8*>(ef_kv);      // [(plane * 4 + octet) * 2 + which][512]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int c = wave * 32 + r;
+  const int n = a.n, ldq = a.ldq;
+  const int RT = (n + 31) >> 5;
+
+  mbvae_bf16x8 l1[4], l2[4];                         // lo planes of the lane's E1 / E2 weight octets
+  {
+    const float* p1 = a.W + (int64_t)c * 64 + 32 * h;
+    const float* p2 = a.W + (int64_t)(256 + c) * 64 + 32 * h;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float4 t = ef_ld4(p1 + 8 * o), u = ef_ld4(p1 + 8 * o + 4), v = ef_ld4(p2 + 8 * o), w = ef_ld4(p2 + 8 * o + 4);
+      const MbvaeSplit3 s1 = mbvae_split8(t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w);
+      const MbvaeSplit3 s2 = mbvae_split8(v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w);
+      wl[((0 * 4 + o) * 2 + 0) * 512 + tid] = s1.hi; wl[((0 * 4 + o) * 2 + 1) * 512 + tid] = s2.hi;
+      wl[((1 * 4 + o) * 2 + 0) * 512 + tid] = s1.mid; wl[((1 * 4 + o) * 2 + 1) * 512 + tid] = s2.mid;
+      l1[o] = s1.lo; l2[o] = s2.lo;
+    }
+  }
+  const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
+  float4 ra[8];
+
+  for (int b = blockIdx.x; b < a.bs; b += gridDim.x) {
+    const int64_t node = (int64_t)b * n;
+    const unsigned long long kmask = __ballot(lane < n && a.mask[node + min(lane, n - 1)] != 0);
+    const float ym1 = a.ye_mul[(int64_t)b * 256 + c] + 1.f;
+    float dya = 0.f, dym = 0.f;
+    for (int mt = 0; mt < RT; ++mt) {
+      float dk[16], dv[16], kv[16], vv[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int j = 32 * mt + 4 * h + (v & 3) + 8 * (v >> 2);
+        dk[v] = 0.f; dv[v] = 0.f;
+        kv[v] = j < n ? a.K[(node + j) * ldq + c] : 0.f;
+        vv[v] = j < n ? a.V[(node + j) * ldq + c] : 0.f;
+      }
+      const unsigned km32 = (unsigned)(kmask >> (32 * mt));
+      const unsigned kml = km32 >> (4 * h);          // bit rr: this lane's key rr of the tile is valid
+      const int jrow = min(32 * mt + r, n - 1);      // the key whose E row this lane feeds to the products
+      {
+        const float* src = a.E + ((node * n + jrow) * 64 + 32 * h);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) ra[p] = ef_ld4(src + 4 * p);
+      }
+      for (int i = 0; i < n; ++i) {
+        const bool qi_ok = (kmask >> i) & 1ull;
+        const int64_t qn = node + i;
+        const float qv = a.Q[qn * ldq + c], ls = a.lse[qn * 256 + c], wv = a.wV[qn * 256 + c], dwv = a.dwV[qn * 256 + c];
+        // this tile's dP words are requested before the products and arrive underneath them
+        const __amdgpu_buffer_rsrc_t rsP =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dP) + qn * n * 256, 0, n * 256 * 4, 0x00020000);
+        const int voffP = (4 * h * 256 + c) * 4, voffE = (4 * h * 512 + c) * 4;
+        float dp[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v)                  // (rows past n are out of the descriptor's range: they read 0)
+          dp[v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, voffP, (32 * mt + (v & 3) + 8 * (v >> 2)) * 1024, 2));
+        asm volatile("" : : : "memory");
+        f32x16 acc1, acc2;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }
+        // ONE operand buffer: an octet is dead once split, the next query row's octet is requested into the same registers
+        const float* nsrc = a.E + (((node + min(i + 1, n - 1)) * n + jrow) * 64 + 32 * h);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float4 t4 = ra[2 * o], u4 = ra[2 * o + 1];
+          asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory");
+          const MbvaeSplit3 as = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);
+          ra[2 * o] = ef_ld4(nsrc + 8 * o); ra[2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);
+          asm volatile("" : : : "memory");
+          if (qi_ok && km32 != 0u) {                  // a tile without a valid pair needs no products (wave-uniform)
+            const mbvae_bf16x8 h1 = wl[((0 * 4 + o) * 2 + 0) * 512 + tid], h2 = wl[((0 * 4 + o) * 2 + 1) * 512 + tid];
+            const mbvae_bf16x8 m1 = wl[((1 * 4 + o) * 2 + 0) * 512 + tid], m2 = wl[((1 * 4 + o) * 2 + 1) * 512 + tid];
+            acc1 = MBVAE_MFMA_BF16(as.lo, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.lo, h2, acc2);
+            acc1 = MBVAE_MFMA_BF16(as.hi, l1[o], acc1); acc2 = MBVAE_MFMA_BF16(as.hi, l2[o], acc2);
+            acc1 = MBVAE_MFMA_BF16(as.mid, m1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, m2, acc2);
+            acc1 = MBVAE_MFMA_BF16(as.mid, h1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, h2, acc2);
+            acc1 = MBVAE_MFMA_BF16(as.hi, m1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, m2, acc2);
+            acc1 = MBVAE_MFMA_BF16(as.hi, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, h2, acc2);
+          }
+        }
+        const __amdgpu_buffer_rsrc_t rsE =
+            __builtin_amdgcn_make_buffer_rsrc(a.dE12 + qn * n * 512, 0, n * 512 * 4, 0x00020000);
+        const float qs = qv * a.scale;
+        float dq = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int rr = (v & 3) + 8 * (v >> 2);
+          const bool key_ok = (kml >> rr) & 1u;
+          const bool pair_ok = qi_ok && key_ok;
+          const float e1 = pair_ok ? acc1[v] : 0.f, e2 = pair_ok ? acc2[v] : 0.f;    // as the forward used them
+          const float qk = qs * kv[v];
+          const float y = qk * (e1 + 1.f) + e2;
+          const float aa = key_ok ? __expf(y - ls) : 0.f;
+          const float dy = dp[v] * ym1 + aa * dwv * (vv[v] - wv);
+          // (rows past n are out of the descriptor's range: the stores are dropped)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy * qk), rsE, voffE, (32 * mt + rr) * 2048, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy), rsE, voffE, (32 * mt + rr) * 2048 + 1024, 2);
+          const float g = dy * (e1 + 1.f);
+          dq += g * (kv[v] * a.scale);
+          dk[v] += g * qs;
+          dv[v] += aa * dwv;
+          dya += dp[v];
+          dym += dp[v] * y;
+        }
+        dq += __shfl_xor(dq, 32);
+        if (h == 0) {
+          float* dst = a.dQ + qn * ldq + c;
+          *dst = mt == 0 ? dq : *dst + dq;           // the first key tile's sum was stored by this very lane
+        }
+        if (i & 1) asm volatile("s_barrier" : : : "memory");   // keep the waves within two rows (they share the E rows in L1)
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int j = 32 * mt + 4 * h + (v & 3) + 8 * (v >> 2);
+        if (j < n) { a.dK[(node + j) * ldq + c] = dk[v]; a.dV[(node + j) * ldq + c] = dv[v]; }
+      }
+    }
+    dya += __shfl_xor(dya, 32);
+    dym += __shfl_xor(dym, 32);
+    if (h == 0) { a.dye_add[(int64_t)b * 256 + c] = dya; a.dye_mul[(int64_t)b * 256 + c] = dym; }
   }
 }
 
@@ -679,7 +833,7 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
                                const float* V, int64_t ldq, const float* ye_add, const float* ye_mul, const uint8_t* mask,
                                float* P, float* wV, float* lse, float* E12, int32_t* work_counter, const int32_t* node_off,
                                const int32_t* graph_order, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
-                               hipStream_t stream, bool bf16out) {
+                               hipStream_t stream, bool bf16out, bool train_form = false) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -709,6 +863,7 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
                   work_counter, node_off, graph_order};
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+  const bool wr = E12 != nullptr || train_form;    // training form: P (and E1|E2 when given) for every pair
   void (*k)(EdgeFusedArgs);
   bool lds_ok;
   if (bf16out) {
@@ -716,11 +871,11 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
     k = edge_fused_fwd_kernel<true, true, true>;
     lds_ok = MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true, true>));
   } else if (split) {
-    k = E12 ? edge_fused_fwd_kernel<true, true> : edge_fused_fwd_kernel<false, true>;
-    lds_ok = E12 ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, true>));
+    k = wr ? edge_fused_fwd_kernel<true, true> : edge_fused_fwd_kernel<false, true>;
+    lds_ok = wr ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, true>));
   } else {
-    k = E12 ? edge_fused_fwd_kernel<true, false> : edge_fused_fwd_kernel<false, false>;
-    lds_ok = E12 ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, false>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, false>));
+    k = wr ? edge_fused_fwd_kernel<true, false> : edge_fused_fwd_kernel<false, false>;
+    lds_ok = wr ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, false>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, false>));
   }
   if (!lds_ok) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
@@ -745,6 +900,44 @@ int mbvae_edge_fused_fwd_bf16(const float* E, const float* W12, const float* b12
                               int64_t dx, float scale, hipStream_t stream) {
   return edge_fused_fwd_impl(E, W12, b12, Q, K, V, ldq, ye_add, ye_mul, mask, (float*)P, wV, lse, (float*)E12, nullptr,
                              nullptr, nullptr, bs, n, de, dx, scale, stream, true);
+}
+
+// Training-form forward WITHOUT the E1|E2 output (P for every pair, wV, lse): to be paired with
+// mbvae_edge_fused_bwd, which recomputes the projection.
+int mbvae_edge_fused_fwd_recompute(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                                   const float* V, int64_t ldq, const float* ye_add, const float* ye_mul,
+                                   const uint8_t* mask, float* P, float* wV, float* lse, int64_t bs, int64_t n, int64_t de,
+                                   int64_t dx, float scale, hipStream_t stream) {
+  // the recomputing backward runs on the bf16 pipeline only, one workgroup per graph
+  if (mbvae_opt(MBVAE_OPT_NO_E12_RECOMPUTE) || mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) || 2 * bs < ef_num_cus()) return MBVAE_EUNSUPPORTED;
+  return edge_fused_fwd_impl(E, W12, b12, Q, K, V, ldq, ye_add, ye_mul, mask, P, wV, lse, nullptr, nullptr, nullptr,
+                             nullptr, bs, n, de, dx, scale, stream, false, true);
+}
+
+// Gradients of the fused block from E itself (the projection output is recomputed, not read): given dP [bs,n,n,dx]
+// and dwV [bs,n,dx] writes dE12 = dE1|dE2 [bs,n,n,2dx] (the gradient w.r.t. the projection output, for the
+// projection's input / weight gradient products), dQ, dK, dV (rows ldq apart) and dye_add, dye_mul [bs,dx].
+// One workgroup per graph: meant for batches of at least about one graph per compute unit.
+// MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.  Bitwise reproducible.
+int mbvae_edge_fused_bwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                         const float* lse, const float* dP, const float* dwV, float* dE12, float* dQ, float* dK, float* dV,
+                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                         hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
+  if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
+  if (ldq < dx || (ldq & 3) || ldq > 0x7fffffff) return MBVAE_EINVAL;
+  const void* ptrs[] = {E, W12, Q, K, V, ye_mul, wV, lse, dP, dwV, dE12, dQ, dK, dV, dye_add, dye_mul};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  if (!mask || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
+  if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
+  if (!MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel)) return MBVAE_ELAUNCH;
+  EdgeFusedBwdArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_mul, mask, wV, lse, dP, dwV, dE12, dQ, dK, dV, dye_add, dye_mul,
+                     (int)bs, (int)n, scale};
+  const int grid = (int)std::min<int64_t>(bs, ef_num_cus());
+  hipLaunchKernelGGL(edge_fused_bwd_kernel, dim3(grid), dim3(512), sizeof(float) * 2 * 64 * 256, stream, a);
+  return mbvae_launch_status();
 }
 
 // out [M,64] = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta with x [M,64], W1 [128,64], W2 [64,128]

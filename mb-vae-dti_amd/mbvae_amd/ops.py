@@ -350,9 +350,17 @@ class _EdgeBlock(torch.autograd.Function):
         else:                           # packed rows; the padding row is never written by the kernel and must be finite
             wV = torch.zeros((QKV.shape[0], dx), dtype=torch.float32, device=dev)
         lse = torch.empty_like(wV)
-        E12 = torch.empty((bs, n, n, N), dtype=store, device=dev) if need_grad else None
         q = QKV.data_ptr()
-        if store == torch.bfloat16:
+        # training, fp32: first choice is the forward that does NOT store E1|E2 (the backward recomputes it from E)
+        recompute = False
+        if need_grad and store == torch.float32 and pack is None:
+            recompute = _lib.call("mbvae_edge_fused_fwd_recompute", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx,
+                                  3 * dx, ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(),
+                                  lse.data_ptr(), bs, n, de, dx, scale, _stream(), allow_unsupported=True)
+        E12 = torch.empty((bs, n, n, N), dtype=store, device=dev) if (need_grad and not recompute) else None
+        if recompute:
+            fused = True
+        elif store == torch.bfloat16:
             _lib.call("mbvae_edge_fused_fwd_bf16", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
                       ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(), lse.data_ptr(),
                       E12.data_ptr(), bs, n, de, dx, scale, _stream())
@@ -383,15 +391,28 @@ class _EdgeBlock(torch.autograd.Function):
             arg = torch.empty((bs, 2, de), dtype=torch.int32, device=dev)
             _lib.call("mbvae_pool_stats_fwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, n * n, de, _stream())
         if need_grad:
-            ctx.save_for_backward(E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse)
+            ctx.save_for_backward(E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse, b)
         ctx.cfg = (n, b is not None, scale)
         return P, wV, stats, E.view_as(E)
 
     @staticmethod
     def backward(ctx, dP, dwV, dstats, dres):
-        E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse = ctx.saved_tensors
+        E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse, b = ctx.saved_tensors
         n, has_bias, scale = ctx.cfg
-        dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV)
+        if E12 is None:                  # the forward did not store E1|E2: gradients from E with the projection recomputed
+            bs, dx = E.shape[0], wV.shape[-1]
+            dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=E.device)
+            dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
+            dE12 = torch.empty((bs, n, n, 2 * dx), dtype=torch.float32, device=E.device)
+            dQKV = torch.empty_like(QKV)
+            dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
+            q, dq = QKV.data_ptr(), dQKV.data_ptr()
+            _lib.call("mbvae_edge_fused_bwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
+                      ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
+                      dE12.data_ptr(), dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, E.shape[-1], dx,
+                      scale, _stream())
+        else:
+            dQKV, dE12, dya, dym = _edge_attn_grads(QKV, E12, ye_mul, m8, wV, lse, scale, dP, dwV)
         dE, dw, db = _edge_input_grads(E, w, m8, stats, arg, n, has_bias, dE12, dstats, dres,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dE, dw, db, dQKV, dya, dym, None, None, None, None

@@ -828,6 +828,56 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
         assert_close(a, b_, rtol=1e-5, what="grads fused vs separate")
 
 
+@pytest.mark.parametrize("bs,n,ragged", [(128, 64, True), (160, 16, False), (130, 33, True), (128, 40, True)])
+def test_edge_block_recompute_backward(ops, bs, n, ragged):
+    """Batches of at least one graph per two compute units train through the pair that never stores E1|E2: the forward
+    writes P / wV / lse only and the backward forms the projection again from E.  Values and all gradients against the
+    plain torch restatement; bitwise equal from run to run; and the storing pair gives the same numbers."""
+    de, dx, H = 64, 256, 8
+    g = torch.Generator().manual_seed(11 * bs + n)
+    sz = torch.randint(1, n + 1, (bs,), generator=g) if ragged else torch.full((bs,), n)
+    sz[0] = n
+    mask = torch.arange(n)[None, :] < sz[:, None]
+    xm = mask.unsqueeze(-1).float()
+    E = torch.randn(bs, n, n, de, generator=g)
+    w = torch.randn(2 * dx, de, generator=g) / math.sqrt(de); b = torch.randn(2 * dx, generator=g) * 0.1
+    QKV = torch.randn(bs, n, 3 * dx, generator=g) * xm
+    ya, ym = torch.randn(bs, dx, generator=g) * 0.3, torch.randn(bs, dx, generator=g) * 0.3
+    pm = (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1).float()
+    cP, cW = torch.randn(bs, n, n, dx, generator=g) * pm, torch.randn(bs, n, dx, generator=g) * xm   # (e_out masks dP likewise)
+    cS, cA = torch.randn(bs, 4 * de, generator=g), torch.randn(bs, n, n, de, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (E, w, b, QKV, ya, ym)]
+    Pr, Wr, Sr = _edge_block_reference(*ref_in, mask, H)
+    ((Pr * cP).sum() + (Wr * cW).sum() + (Sr * cS).sum() + (ref_in[0] * cA).sum()).backward()
+
+    def run():
+        ins = [t.clone().cuda().requires_grad_(True) for t in (E, w, b, QKV, ya, ym)]
+        _lib.PROFILE = {}
+        try:
+            P, wV, stats, alias = ops.edge_block(*ins, mask.cuda(), H)
+            ((P * cP.cuda()).sum() + (wV * cW.cuda()).sum() + (stats * cS.cuda()).sum() + (alias * cA.cuda()).sum()).backward()
+            torch.cuda.synchronize()
+            called = {name for name, _ in _lib.PROFILE}
+        finally:
+            _lib.PROFILE = None
+        return P.detach(), wV.detach(), [t.grad for t in ins], called
+
+    P, wV, grads, called = run()
+    assert {"mbvae_edge_fused_fwd_recompute", "mbvae_edge_fused_bwd"} <= called and "mbvae_edge_attn_bwd" not in called
+    assert_close(P, Pr, what="P"); assert_close(wV * xm.cuda(), Wr * xm, what="wV")
+    names = ("dE", "dw12", "db12", "dQKV", "dye_add", "dye_mul")
+    for got, t, name in zip(grads, ref_in, names):
+        assert_close(got, t.grad, what=name)
+    P2, wV2, grads2, _ = run()
+    assert torch.equal(P, P2) and torch.equal(wV, wV2) and all(torch.equal(a, b_) for a, b_ in zip(grads, grads2)), "not reproducible"
+    with _lib.option("NO_E12_RECOMPUTE", 1):
+        P1, wV1, grads1, called1 = run()
+    assert "mbvae_edge_attn_bwd" in called1 and "mbvae_edge_fused_bwd" not in called1
+    assert torch.equal(P1, P) and torch.equal(wV1, wV)          # the same forward kernel, minus the E1|E2 stores
+    for a, b_, name in zip(grads1, grads, names):
+        assert_close(a, b_, what=name + " storing vs recomputing")
+
+
 def test_train_step_gradients_are_bitwise_reproducible():
     """Two runs of the same denoiser step (same weights, data, dropout seeds) at the benchmark widths give bit-identical
     losses and gradients: no kernel on the path accumulates with floating-point atomics (the attention backward sums
