@@ -211,7 +211,10 @@ def main():
         ea_bytes = {"mbvae_edge_attn_bwd": s * (5 * bs * n * n * dx + 8 * bs * n * dx),      # E1,E2,dP in; dE1,dE2 out
                     "mbvae_edge_attn_fwd": s * (3 * bs * n * n * dx + 4 * bs * n * dx + 2 * bs * dx) + bs * n,
                     # projection inside the attention forward, training form: E in; E1|E2 and P out
-                    "mbvae_edge_fused_fwd": s * (bs * n * n * (de + 3 * dx) + 4 * bs * n * dx)}
+                    "mbvae_edge_fused_fwd": s * (bs * n * n * (de + 3 * dx) + 4 * bs * n * dx),
+                    # the default training pair: forward E in, P out; backward E, dP in, dE1|dE2 out (E1|E2 recomputed)
+                    "mbvae_edge_fused_fwd_recompute": s * (bs * n * n * (de + dx) + 4 * bs * n * dx),
+                    "mbvae_edge_fused_bwd": s * (bs * n * n * (de + 3 * dx) + 10 * bs * n * dx)}
         cands = []
         for (name, tag), evs in profile.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)

@@ -61,10 +61,37 @@ with torch.enable_grad():
         mark("mbvae_edge_fused_fwd:inference")
         ops.edge_block(Ef, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)
     Eg = Ef.clone().requires_grad_(True)
-    mark("mbvae_edge_fused_fwd")
-    Pf = ops.edge_block(Eg, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)
+    from mbvae_amd import _lib
+    with _lib.option("NO_E12_RECOMPUTE", 1):       # training form that stores E1|E2 (small batches, bf16 storage)
+        mark("mbvae_edge_fused_fwd")
+        Pf = ops.edge_block(Eg, w12, b12, QKV.detach(), ya.detach(), ym.detach(), mask, 8)
+        mark("setup")
+        del Pf
+    # the default training pair: forward without the E1|E2 output, backward recomputing it (entry points called directly
+    # so that each segment holds exactly one kernel)
+    st = torch.cuda.current_stream().cuda_stream
+    m8 = mask.view(torch.uint8)
+    q = QKV.detach()
+    Pr = torch.empty(bs, n, n, dx, device=dev); wVr = torch.empty(bs, n, dx, device=dev); lser = torch.empty(bs, n, dx, device=dev)
+    args_f = (Ef.data_ptr(), w12.data_ptr(), b12.data_ptr(), q.data_ptr(), q.data_ptr() + 4 * dx, q.data_ptr() + 8 * dx, 3 * dx,
+              ya.data_ptr(), ym.data_ptr(), m8.data_ptr(), Pr.data_ptr(), wVr.data_ptr(), lser.data_ptr(), bs, n, de, dx, 32 ** -0.5, st)
+    _lib.call("mbvae_edge_fused_fwd_recompute", *args_f)
+    torch.cuda.synchronize()
+    mark("mbvae_edge_fused_fwd_recompute")
+    _lib.call("mbvae_edge_fused_fwd_recompute", *args_f)
     mark("setup")
-    del Pf, Ef, Eg
+    dPr = torch.randn(bs, n, n, dx, device=dev); dWr = torch.randn(bs, n, dx, device=dev)
+    dE12 = torch.empty(bs, n, n, 2 * dx, device=dev); dq = torch.empty(bs, n, 3 * dx, device=dev)
+    dya, dym = torch.empty(bs, dx, device=dev), torch.empty(bs, dx, device=dev)
+    args_b = (Ef.data_ptr(), w12.data_ptr(), b12.data_ptr(), q.data_ptr(), q.data_ptr() + 4 * dx, q.data_ptr() + 8 * dx, 3 * dx,
+              ym.data_ptr(), m8.data_ptr(), wVr.data_ptr(), lser.data_ptr(), dPr.data_ptr(), dWr.data_ptr(), dE12.data_ptr(),
+              dq.data_ptr(), dq.data_ptr() + 4 * dx, dq.data_ptr() + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, de, dx, 32 ** -0.5, st)
+    _lib.call("mbvae_edge_fused_bwd", *args_b)
+    torch.cuda.synchronize()
+    mark("mbvae_edge_fused_bwd")
+    _lib.call("mbvae_edge_fused_bwd", *args_b)
+    mark("setup")
+    del Pr, dPr, dE12, Ef, Eg
     x = torch.randn(bs, n, n, de, device=dev, requires_grad=True); r = torch.randn_like(x).requires_grad_(True)
     g, b = torch.ones(de, device=dev, requires_grad=True), torch.zeros(de, device=dev, requires_grad=True)
     dy = torch.randn_like(x); ds = torch.randn(bs, 4 * de, device=dev)
