@@ -165,7 +165,7 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fp32 products on the bf16 matrix pipeline.  gfx950 runs v_mfma_f32_32x32x2_f32 at 256 flop/clk/CU-SIMD and
+// fp32 products on the bf16 matrix pipeline.  gfx950 runs v_mfma_f32_32x32x2_f32 at 64 flop/clk per SIMD and
 // v_mfma_f32_32x32x16_bf16 at 1024: an fp32 value cut by TRUNCATION into three bf16 words (hi + mid + lo, 8 mantissa
 // bits each, so the three sum to the value exactly) lets a product of two fp32 operands be formed from six bf16
 // MFMAs - hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the three dropped terms are below 2^-24 of the product - with
