@@ -285,6 +285,13 @@ int mbvae_linear_bwd_weight_bf16(const void* dy, int dy_bf16, int64_t lddy, cons
 int mbvae_dense_from_ids(const int8_t* atoms, const int8_t* bonds, float* X, float* E, uint8_t* mask, int64_t bs,
                          int64_t n, int64_t cx, int64_t ce, mbvae_stream_t stream);
 
+/* ---- k-cycle counts (n <= 64) ----------------------------------------------------------------------------
+ * Replaces KNodeCycles.k_cycles (k3/k4/k5/k6_cycle), mb_vae_dti/training/diffusion/augmentation.py:177-250: five
+ * batched matrix products and ~30 element-wise launches become one kernel.  A [bs,n,n] adjacency ->
+ * xc [bs,n,3] (3-, 4-, 5-cycles through each node), yc [bs,4] (3-, 4-, 5-, 6-cycles per graph), before the
+ * reference's /10 and clamp.  MBVAE_EUNSUPPORTED for n > 64. */
+int mbvae_cycle_counts(const float* A, float* xc, float* yc, int64_t bs, int64_t n, mbvae_stream_t stream);
+
 /* ---- batched symmetric eigendecomposition (n <= 64) ----------------------------------------------------
  * Replaces torch.linalg.eigh on the graph Laplacians, mb_vae_dti/training/diffusion/augmentation.py:68.
  * A [bs,n,n] symmetric -> W [bs,n] ascending, V [bs,n,n] eigenvectors in columns (signs / degenerate

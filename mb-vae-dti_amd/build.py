@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmbvae_hip.so")
-SOURCES = ["gemm.hip", "edge_attn.hip", "edge_fused.hip", "rowops.hip", "loss.hip", "diffusion.hip", "eigen.hip"]
+SOURCES = ["gemm.hip", "edge_attn.hip", "edge_fused.hip", "rowops.hip", "loss.hip", "diffusion.hip", "eigen.hip", "cycles.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=on"]
 
 

@@ -753,7 +753,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   if (mbvae_opt(MBVAE_OPT_NO_TSGEMM)) return MBVAE_EUNSUPPORTED;
   const bool aligned = (((uintptr_t)g.A | (uintptr_t)g.a_gate) & 15) == 0 && (g.lda & (g.a_bf16 ? 7 : 3)) == 0;
   const bool bf16 = g.a_bf16 || g.c_bf16;
-  if (g.b_bf16 || (bf16 && (g.a_gate || g.act || g.drop_p > 0.f || g.bias && g.c_bf16 || g.a_gate_scale != 1.f)))
+  if (g.b_bf16 || (bf16 && (g.a_gate || g.act || g.drop_p > 0.f || (g.bias && g.c_bf16) || g.a_gate_scale != 1.f)))
     return MBVAE_EUNSUPPORTED;
   if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)

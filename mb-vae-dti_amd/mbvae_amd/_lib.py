@@ -19,6 +19,7 @@ SIGNATURES = {
     "mbvae_get_option": [c_char_p],
     "mbvae_linear_fwd": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P, _I, _I, _F, _U, _I, _P, _L, _P],
     "mbvae_linear_bwd_input": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _P, _L, _P],
+    "mbvae_cycle_counts": [_P, _P, _P, _L, _L, _P],
     "mbvae_linear_fwd_bf16": [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "mbvae_linear_bwd_input_bf16": [_P, _I, _L, _P, _P, _P, _I, _L, _L, _L, _L, _P, _I, _I, _P],
     "mbvae_linear_bwd_weight_bf16": [_P, _I, _L, _P, _I, _L, _P, _P, _L, _L, _L, _P, _I, _I, _P, _L, _P],

@@ -13,7 +13,10 @@ def _diag(M):
 
 
 def cycle_counts(A):
-    """Per-node 3/4/5-cycle and per-graph 3/4/5/6-cycle counts from adjacency A [bs,n,n] (augmentation.py:177-250)."""
+    """Per-node 3/4/5-cycle and per-graph 3/4/5/6-cycle counts from adjacency A [bs,n,n] (augmentation.py:177-250).
+    One HIP kernel for n <= 64; larger graphs take the same formulas as batched device matmuls."""
+    if A.is_cuda and A.shape[-1] <= 64 and A.dtype == torch.float32:
+        return ops.cycle_counts(A)
     d = A.sum(-1)
     A2 = A @ A
     A3 = A2 @ A

@@ -830,3 +830,15 @@ def reverse_sample(logitsX, logitsE, Xt, Et, node_mask, beta_t, abar_s, abar_t, 
               expE.data_ptr(), Xc.data_ptr(), Ec.data_ptr(), Xs.data_ptr(), Es.data_ptr(), _ptr(pX), _ptr(pE), bs, n, cx, ce,
               _stream())
     return (Xc, Ec, Xs, Es, pX, pE) if want_probs else (Xc, Ec, Xs, Es)
+
+
+# ------------------------------------------------------------------------------------------------ cycle counts
+def cycle_counts(A):
+    """(per-node 3/4/5-cycle counts [bs,n,3], per-graph 3/4/5/6-cycle counts [bs,4]) of adjacency matrices A [bs,n,n],
+    n <= 64 (no gradient: the extra features are inputs of the denoiser)."""
+    A = _f32c(A.detach(), "A")
+    bs, n = A.shape[0], A.shape[-1]
+    xc = torch.empty((bs, n, 3), dtype=torch.float32, device=A.device)
+    yc = torch.empty((bs, 4), dtype=torch.float32, device=A.device)
+    _lib.call("mbvae_cycle_counts", A.data_ptr(), xc.data_ptr(), yc.data_ptr(), bs, n, _stream())
+    return xc, yc

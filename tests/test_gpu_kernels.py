@@ -457,6 +457,20 @@ def test_sym_eig(ops, bs, n):
     assert float((V.transpose(1, 2) @ V - eye).abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("bs,n,p", [(64, 64, 0.06), (7, 33, 0.15), (5, 9, 0.4), (3, 2, 1.0), (2, 1, 0.0), (300, 40, 0.08)])
+def test_cycle_counts_kernel_matches_adjacency_power_formulas(ops, bs, n, p):
+    """One-kernel cycle counts against the oracle's restatement of the reference's adjacency-power formulas on random
+    molecule-like graphs (symmetric 0/1 adjacency, no self loops): integer counts, so the match is exact."""
+    from oracle.features import cycle_features
+    g = torch.Generator().manual_seed(100 * n + bs)
+    U = (torch.rand(bs, n, n, generator=g) < p).float().triu(1)
+    A = U + U.transpose(1, 2)
+    xr, yr = cycle_features(A.double())
+    xg, yg = ops.cycle_counts(A.cuda())
+    assert torch.equal(xg.cpu(), xr.float()), "per-node 3/4/5-cycle counts"
+    assert torch.equal(yg.cpu(), yr.float()), "per-graph 3/4/5/6-cycle counts"
+
+
 def test_extra_features_golden():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
