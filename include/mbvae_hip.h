@@ -262,6 +262,17 @@ int mbvae_edge_attn_bwd_bf16(const float* Q, const float* K, const float* V, int
                              uint16_t* dE2, float* dQ, float* dK, float* dV, float* dye_add, float* dye_mul,
                              int64_t bs, int64_t n, int64_t dx, float scale, void* workspace, int64_t ws_bytes,
                              mbvae_stream_t stream);
+/* the recomputing pair in this mode: P, dP and dE1|dE2 are bf16, E1|E2 is never stored */
+int mbvae_edge_fused_fwd_recompute_bf16(const float* E, const float* W12, const float* b12, const float* Q,
+                                        const float* K, const float* V, int64_t ldq, const float* ye_add,
+                                        const float* ye_mul, const uint8_t* mask, uint16_t* P, float* wV, float* lse,
+                                        int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                                        mbvae_stream_t stream);
+int mbvae_edge_fused_bwd_bf16(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                              const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                              const float* lse, const uint16_t* dP, const float* dwV, uint16_t* dE12, float* dQ,
+                              float* dK, float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de,
+                              int64_t dx, float scale, mbvae_stream_t stream);
 /* y (fp32) = rowmask(x (bf16) @ w^T + bias): the e_out projection reading P */
 int mbvae_linear_fwd_bf16(const uint16_t* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
                           int64_t M, int64_t K, int64_t N, const uint8_t* mask, int mask_mode, int n_nodes,

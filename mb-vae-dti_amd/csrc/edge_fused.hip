@@ -312,7 +312,10 @@ struct EdgeFusedBwdArgs {
   int sync_mask;            // the waves of a workgroup meet after every query row i with (i & sync_mask) == sync_mask
 };
 
+// BF16: dP is read and dE1|dE2 written as bf16 (the opt-in bf16 storage mode); everything else as in fp32.
+template <bool BF16>
 __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a) {
+  constexpr int SS = BF16 ? 2 : 4;                  // bytes per dP / dE1|dE2 element
   // Register budget (256 per lane at 512 threads): the lane's W12 slice as three bf16 planes would take 96.  Its hi and
   // mid planes therefore live in LDS - 16 bytes per (plane, octet, E1/E2, thread), written and read by their owner only,
   // so no barrier guards them - and only the lo planes stay in registers.  K and V need no LDS here: with the key
@@ -370,13 +373,16 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
         const int64_t qn = node + i;
         const float qv = a.Q[qn * ldq + c], ls = a.lse[qn * 256 + c], wv = a.wV[qn * 256 + c], dwv = a.dwV[qn * 256 + c];
         // this tile's dP words are requested before the products and arrive underneath them
-        const __amdgpu_buffer_rsrc_t rsP =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dP) + qn * n * 256, 0, n * 256 * 4, 0x00020000);
-        const int voffP = (4 * h * 256 + c) * 4, voffE = (4 * h * 512 + c) * 4;
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(const_cast<float*>(a.dP)) + qn * n * 256 * SS, 0, n * 256 * SS, 0x00020000);
+        const int voffP = (4 * h * 256 + c) * SS, voffE = (4 * h * 512 + c) * SS;
         float dp[16];
 #pragma unroll
-        for (int v = 0; v < 16; ++v)                  // (rows past n are out of the descriptor's range: they read 0)
-          dp[v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, voffP, (32 * mt + (v & 3) + 8 * (v >> 2)) * 1024, 2));
+        for (int v = 0; v < 16; ++v) {                // (rows past n are out of the descriptor's range: they read 0)
+          const int so = (32 * mt + (v & 3) + 8 * (v >> 2)) * 256 * SS;
+          if (BF16) dp[v] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsP, voffP, so, 2) << 16);
+          else dp[v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, voffP, so, 2));
+        }
         asm volatile("" : : : "memory");
         f32x16 acc1, acc2;
 #pragma unroll
@@ -401,8 +407,8 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
             acc1 = MBVAE_MFMA_BF16(as.hi, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, h2, acc2);
           }
         }
-        const __amdgpu_buffer_rsrc_t rsE =
-            __builtin_amdgcn_make_buffer_rsrc(a.dE12 + qn * n * 512, 0, n * 512 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.dE12) + qn * n * 512 * SS, 0, n * 512 * SS, 0x00020000);
         const float qs = qv * a.scale;
         float dq = 0.f;
 #pragma unroll
@@ -416,8 +422,13 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
           const float aa = key_ok ? __expf(y - ls) : 0.f;
           const float dy = dp[v] * ym1 + aa * dwv * (vv[v] - wv);
           // (rows past n are out of the descriptor's range: the stores are dropped)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy * qk), rsE, voffE, (32 * mt + rr) * 2048, 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy), rsE, voffE, (32 * mt + rr) * 2048 + 1024, 2);
+          if (BF16) {
+            __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(dy * qk), rsE, voffE, (32 * mt + rr) * 1024, 2);
+            __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(dy), rsE, voffE, (32 * mt + rr) * 1024 + 512, 2);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy * qk), rsE, voffE, (32 * mt + rr) * 2048, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dy), rsE, voffE, (32 * mt + rr) * 2048 + 1024, 2);
+          }
           const float g = dy * (e1 + 1.f);
           dq += g * (kv[v] * a.scale);
           dk[v] += g * qs;
@@ -868,7 +879,7 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
   void (*k)(EdgeFusedArgs);
   bool lds_ok;
   if (bf16out) {
-    if (!E12) return MBVAE_EINVAL;                   // bf16 storage is a training-form feature
+    if (!wr) return MBVAE_EINVAL;                    // bf16 storage is a training-form feature
     k = edge_fused_fwd_kernel<true, true, true>;
     lds_ok = MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true, true>));
   } else if (split) {
@@ -920,11 +931,11 @@ int mbvae_edge_fused_fwd_recompute(const float* E, const float* W12, const float
 // projection's input / weight gradient products), dQ, dK, dV (rows ldq apart) and dye_add, dye_mul [bs,dx].
 // One workgroup per graph: meant for batches of at least about one graph per compute unit.
 // MBVAE_EUNSUPPORTED unless de == 64, dx == 256, n <= 64.  Bitwise reproducible.
-int mbvae_edge_fused_bwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
-                         const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
-                         const float* lse, const float* dP, const float* dwV, float* dE12, float* dQ, float* dK, float* dV,
-                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
-                         hipStream_t stream) {
+static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                               const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                               const float* lse, const void* dP, const float* dwV, void* dE12, float* dQ, float* dK, float* dV,
+                               float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                               hipStream_t stream, bool bf16) {
   (void)hipGetLastError();
   if (bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (de != 64 || dx != 256 || n > 64 || bs > 0x7fffffff / 8) return MBVAE_EUNSUPPORTED;
@@ -933,13 +944,41 @@ int mbvae_edge_fused_bwd(const float* E, const float* W12, const float* b12, con
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if (!mask || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
   if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
-  if (!MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel)) return MBVAE_ELAUNCH;
-  EdgeFusedBwdArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_mul, mask, wV, lse, dP, dwV, dE12, dQ, dK, dV, dye_add, dye_mul,
-                     (int)bs, (int)n, scale, 7};   // every 8 rows: measured 2: 7.26, 4: 7.28, 8: 6.95, never: 8.17 ms per step
+  if (!(bf16 ? MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<false>))) return MBVAE_ELAUNCH;
+  EdgeFusedBwdArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_mul, mask, wV, lse, (const float*)dP, dwV, (float*)dE12, dQ, dK, dV,
+                     dye_add, dye_mul, (int)bs, (int)n, scale, 7};   // every 8 rows: measured 2: 7.26, 4: 7.28, 8: 6.95, never: 8.17 ms per step
   if (const int sy = mbvae_opt(MBVAE_OPT_EFB_SYNC); sy > 0) a.sync_mask = sy - 1;
   const int grid = (int)std::min<int64_t>(bs, ef_num_cus());
-  hipLaunchKernelGGL(edge_fused_bwd_kernel, dim3(grid), dim3(512), sizeof(float) * 2 * 64 * 256, stream, a);
+  auto k = bf16 ? edge_fused_bwd_kernel<true> : edge_fused_bwd_kernel<false>;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), sizeof(float) * 2 * 64 * 256, stream, a);
   return mbvae_launch_status();
+}
+
+int mbvae_edge_fused_bwd(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                         const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                         const float* lse, const float* dP, const float* dwV, float* dE12, float* dQ, float* dK, float* dV,
+                         float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx, float scale,
+                         hipStream_t stream) {
+  return edge_fused_bwd_impl(E, W12, b12, Q, K, V, ldq, ye_mul, mask, wV, lse, dP, dwV, dE12, dQ, dK, dV, dye_add, dye_mul, bs, n,
+                             de, dx, scale, stream, false);
+}
+
+// The recomputing pair in the bf16 storage mode: P (forward), dP and dE1|dE2 (backward) are bf16 in memory.
+int mbvae_edge_fused_fwd_recompute_bf16(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                                        const float* V, int64_t ldq, const float* ye_add, const float* ye_mul,
+                                        const uint8_t* mask, uint16_t* P, float* wV, float* lse, int64_t bs, int64_t n,
+                                        int64_t de, int64_t dx, float scale, hipStream_t stream) {
+  if (mbvae_opt(MBVAE_OPT_NO_E12_RECOMPUTE) || 2 * bs < ef_num_cus()) return MBVAE_EUNSUPPORTED;
+  return edge_fused_fwd_impl(E, W12, b12, Q, K, V, ldq, ye_add, ye_mul, mask, (float*)P, wV, lse, nullptr, nullptr, nullptr,
+                             nullptr, bs, n, de, dx, scale, stream, true, true);
+}
+int mbvae_edge_fused_bwd_bf16(const float* E, const float* W12, const float* b12, const float* Q, const float* K,
+                              const float* V, int64_t ldq, const float* ye_mul, const uint8_t* mask, const float* wV,
+                              const float* lse, const uint16_t* dP, const float* dwV, uint16_t* dE12, float* dQ, float* dK,
+                              float* dV, float* dye_add, float* dye_mul, int64_t bs, int64_t n, int64_t de, int64_t dx,
+                              float scale, hipStream_t stream) {
+  return edge_fused_bwd_impl(E, W12, b12, Q, K, V, ldq, ye_mul, mask, wV, lse, dP, dwV, dE12, dQ, dK, dV, dye_add, dye_mul, bs, n,
+                             de, dx, scale, stream, true);
 }
 
 // out [M,64] = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta with x [M,64], W1 [128,64], W2 [64,128]

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mbvae_edge_attn_bwd_bf16": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 13 + [_L, _L, _L, _F, _P, _L, _P],
     "mbvae_edge_fused_fwd_recompute": [_P] * 6 + [_L] + [_P] * 6 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_fused_bwd": [_P] * 6 + [_L] + [_P] * 12 + [_L, _L, _L, _L, _F, _P],
+    "mbvae_edge_fused_fwd_recompute_bf16": [_P] * 6 + [_L] + [_P] * 6 + [_L, _L, _L, _L, _F, _P],
+    "mbvae_edge_fused_bwd_bf16": [_P] * 6 + [_L] + [_P] * 12 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_fused_fwd_bf16": [_P] * 6 + [_L] + [_P] * 7 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_ffn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],

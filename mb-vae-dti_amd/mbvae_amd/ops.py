@@ -353,8 +353,9 @@ class _EdgeBlock(torch.autograd.Function):
         q = QKV.data_ptr()
         # training, fp32: first choice is the forward that does NOT store E1|E2 (the backward recomputes it from E)
         recompute = False
-        if need_grad and store == torch.float32 and pack is None:
-            recompute = _lib.call("mbvae_edge_fused_fwd_recompute", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx,
+        if need_grad and pack is None:
+            recompute = _lib.call("mbvae_edge_fused_fwd_recompute_bf16" if store == torch.bfloat16 else "mbvae_edge_fused_fwd_recompute",
+                                  E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx,
                                   3 * dx, ye_add.data_ptr(), ye_mul.data_ptr(), m8.data_ptr(), P.data_ptr(), wV.data_ptr(),
                                   lse.data_ptr(), bs, n, de, dx, scale, _stream(), allow_unsupported=True)
         E12 = torch.empty((bs, n, n, N), dtype=store, device=dev) if (need_grad and not recompute) else None
@@ -393,6 +394,7 @@ class _EdgeBlock(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(E, w, m8, stats, arg, QKV, E12, ye_mul, wV, lse, b)
         ctx.cfg = (n, b is not None, scale)
+        ctx.store = store
         return P, wV, stats, E.view_as(E)
 
     @staticmethod
@@ -401,13 +403,17 @@ class _EdgeBlock(torch.autograd.Function):
         n, has_bias, scale = ctx.cfg
         if E12 is None:                  # the forward did not store E1|E2: gradients from E with the projection recomputed
             bs, dx = E.shape[0], wV.shape[-1]
-            dP = _f32c(dP) if dP is not None else torch.zeros((bs, n, n, dx), dtype=torch.float32, device=E.device)
+            bf16 = ctx.store == torch.bfloat16
+            if dP is None:
+                dP = torch.zeros((bs, n, n, dx), dtype=ctx.store, device=E.device)
+            else:
+                dP = dP.to(torch.bfloat16).contiguous() if bf16 else _f32c(dP)
             dwV = _f32c(dwV) if dwV is not None else torch.zeros_like(wV)
-            dE12 = torch.empty((bs, n, n, 2 * dx), dtype=torch.float32, device=E.device)
+            dE12 = torch.empty((bs, n, n, 2 * dx), dtype=ctx.store, device=E.device)
             dQKV = torch.empty_like(QKV)
             dya, dym = torch.empty_like(ye_mul), torch.empty_like(ye_mul)
             q, dq = QKV.data_ptr(), dQKV.data_ptr()
-            _lib.call("mbvae_edge_fused_bwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
+            _lib.call("mbvae_edge_fused_bwd_bf16" if bf16 else "mbvae_edge_fused_bwd", E.data_ptr(), w.data_ptr(), _ptr(b), q, q + 4 * dx, q + 8 * dx, 3 * dx,
                       ye_mul.data_ptr(), m8.data_ptr(), wV.data_ptr(), lse.data_ptr(), dP.data_ptr(), dwV.data_ptr(),
                       dE12.data_ptr(), dq, dq + 4 * dx, dq + 8 * dx, dya.data_ptr(), dym.data_ptr(), bs, n, E.shape[-1], dx,
                       scale, _stream())

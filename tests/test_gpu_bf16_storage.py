@@ -158,3 +158,39 @@ def test_bf16_storage_train_steps_track_fp32(ops):
             ops.set_bf16_storage(False)
     for a, b in zip(losses[False], losses[True]):
         assert math.isfinite(b) and abs(a - b) <= BF16_RTOL * abs(a), (losses[False], losses[True])
+
+
+def test_bf16_recomputing_pair_matches_fp32_edge_block(ops):
+    """Batches of at least one graph per two compute units take the recomputing pair in bf16 mode as well (P, dP and
+    dE1|dE2 in bf16, E1|E2 never stored): forward element-wise and gradients in relative L2 within 2e-2 of fp32."""
+    from mbvae_amd import _lib
+    bs, n, dx, de = 128, 40, 256, 64
+    g = torch.Generator().manual_seed(5)
+    mask = _ragged(bs, n, g)
+    E = torch.randn(bs, n, n, de, generator=g).cuda()
+    w = (torch.randn(2 * dx, de, generator=g) / 8).cuda(); b = (torch.randn(2 * dx, generator=g) * 0.1).cuda()
+    QKV = torch.randn(bs, n, 3 * dx, generator=g).cuda() * 0.6
+    ya = torch.randn(bs, dx, generator=g).cuda() * 0.3; ym = torch.randn(bs, dx, generator=g).cuda() * 0.3
+    pm = (mask.unsqueeze(1) & mask.unsqueeze(2)).unsqueeze(-1).float()
+    cP = torch.randn(bs, n, n, dx, generator=g).cuda() * pm; cW = torch.randn(bs, n, dx, generator=g).cuda()
+    res, called = {}, {}
+    for mode in (False, True):
+        ops.set_bf16_storage(mode)
+        _lib.PROFILE = {}
+        try:
+            ins = [t.clone().requires_grad_(True) for t in (E, w, b, QKV, ya, ym)]
+            P, wV, stats, _ = ops.edge_block(*ins, mask, 8)
+            ((P.float() * cP).sum() + (wV * cW).sum()).backward()
+            torch.cuda.synchronize()
+            called[mode] = {name for name, _ in _lib.PROFILE}
+        finally:
+            _lib.PROFILE = None
+            ops.set_bf16_storage(False)
+        res[mode] = [P.detach().float() * pm, wV.detach()] + [t.grad for t in ins]
+    assert {"mbvae_edge_fused_fwd_recompute_bf16", "mbvae_edge_fused_bwd_bf16"} <= called[True]
+    assert {"mbvae_edge_fused_fwd_recompute", "mbvae_edge_fused_bwd"} <= called[False]
+    assert P.dtype == torch.bfloat16
+    assert_close(res[True][0], res[False][0], rtol=BF16_RTOL, what="P"); assert_close(res[True][1], res[False][1], rtol=BF16_RTOL, what="wV")
+    for a, r, name in zip(res[True][2:], res[False][2:], ("dE", "dw12", "db12", "dQKV", "dye_add", "dye_mul")):
+        err = float((a.double() - r.double()).norm() / r.double().norm())
+        assert err <= BF16_RTOL, f"{name}: relative L2 error {err:.3e}"
