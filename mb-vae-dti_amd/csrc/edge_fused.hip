@@ -27,6 +27,7 @@ struct EdgeFusedArgs {
   int* queue;      // optional work counter (zeroed before the launch): workgroups take tasks in order as they finish
   const int* node_off;   // optional [bs+1]: Q, K, V, wV, lse hold only the valid nodes, graph b's at rows node_off[b]..
   const int* graph_order;   // optional [bs]: the k-th group of tasks works on graph graph_order[k] (largest graphs first)
+  int stagger;              // training forms: 0 all waves in phase; 1 waves 0-3 vs 4-7 half a tile apart; 2 even vs odd waves
 };
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   const int ntasks = a.bs * a.ichunks;
   const int ipc = (n + a.ichunks - 1) / a.ichunks;   // query rows per task
   const bool st_e12 = a.E12 != nullptr;            // training form without E1|E2 output: the backward recomputes it
+  // Two waves share a SIMD.  In phase they would both multiply (queueing on the matrix pipe), then both run their
+  // element-wise epilogues (queueing on the vector ALU).  The rendezvous therefore sits at DIFFERENT points of the tile
+  // for the two groups - after the products for group A, after the epilogue for group B - which keeps the groups half
+  // a tile apart: while one multiplies the other runs its epilogue.  Same number of barriers per tile for every wave.
+  const bool grpB = a.stagger == 1 ? wave >= 4 : (a.stagger == 2 ? (wave & 1) != 0 : false);
+  const bool stag = WRITE_E12 && a.stagger != 0;
 
   float4 ra[2][8];
   float qv[2];
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           }                                                                                            \
         }                                                                                              \
       }                                                                                                \
+      if (stag && !grpB) asm volatile("s_barrier" : : : "memory");                                     \
       const float qs = qv[S] * a.scale;                                                                \
       const float* Kp = Ks + (32 * mt + 4 * h) * 256 + c;                                              \
       const float* Vp = Vs + (32 * mt + 4 * h) * 256 + c;                                              \
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
         }                                                                                              \
         if (h == 0) { a.wV[(pnode + i) * 256 + c] = o; a.lse[(pnode + i) * 256 + c] = s; }             \
       }                                                                                                \
+      if (stag && grpB) asm volatile("s_barrier" : : : "memory");                                      \
     }
 
     EF_FETCH(0, 0)
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       // behind finds them evicted from L1/L2 and fetches them from HBM again (measured: E read 2.7 times).
       // Pure rendezvous, no data is exchanged, so no memory counters are waited for.  Only in the HBM-bound form
       // that also writes E1|E2; the inference form is bound by the products and ran 2 % slower in step.
-      if (WRITE_E12) asm volatile("s_barrier" : : : "memory");
+      if (WRITE_E12 && !stag) asm volatile("s_barrier" : : : "memory");
     }
 #undef EF_FETCH
 #undef EF_TILE
@@ -310,6 +319,8 @@ struct EdgeFusedBwdArgs {
   float* dE12; float* dQ; float* dK; float* dV; float* dye_add; float* dye_mul;
   int bs, n; float scale;
   int sync_mask;            // the waves of a workgroup meet after every query row i with (i & sync_mask) == sync_mask
+  int stagger;              // 0: all waves meet at the end of the row; 1: waves 0-3 meet after their products, waves 4-7 after
+                            // their epilogue (half a tile apart: one group multiplies while the other runs its epilogue); 2: even / odd
 };
 
 // BF16: dP is read and dE1|dE2 written as bf16 (the opt-in bf16 storage mode); everything else as in fp32.
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
     }
   }
   const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
+  const bool grpB = a.stagger == 1 ? wave >= 4 : (a.stagger == 2 ? (wave & 1) != 0 : false);
   float4 ra[8];
 
   for (int b = blockIdx.x; b < a.bs; b += gridDim.x) {
@@ -407,6 +419,8 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
             acc1 = MBVAE_MFMA_BF16(as.hi, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, h2, acc2);
           }
         }
+        const bool meet = (i & a.sync_mask) == a.sync_mask;
+        if (meet && a.stagger != 0 && !grpB) asm volatile("s_barrier" : : : "memory");
         const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char*>(a.dE12) + qn * n * 512 * SS, 0, n * 512 * SS, 0x00020000);
         const float qs = qv * a.scale;
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
           float* dst = a.dQ + qn * ldq + c;
           *dst = mt == 0 ? dq : *dst + dq;           // the first key tile's sum was stored by this very lane
         }
-        if ((i & a.sync_mask) == a.sync_mask) asm volatile("s_barrier" : : : "memory");   // keep the waves together: they share the E rows in L1
+        if (meet && (a.stagger == 0 || grpB)) asm volatile("s_barrier" : : : "memory");   // keep the waves together: they share the E rows in L1
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -872,7 +886,8 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
       return MBVAE_EINVAL;
   }
   EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
-                  work_counter, node_off, graph_order};
+                  work_counter, node_off, graph_order, 1};
+  if (const int sg = mbvae_opt(MBVAE_OPT_EF_STAGGER); sg > 0) a.stagger = sg == 3 ? 0 : sg;
   const size_t smem = sizeof(float) * 2 * 64 * 256;
   const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
   const bool wr = E12 != nullptr || train_form;    // training form: P (and E1|E2 when given) for every pair
@@ -946,8 +961,10 @@ static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b1
   if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
   if (!(bf16 ? MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<false>))) return MBVAE_ELAUNCH;
   EdgeFusedBwdArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_mul, mask, wV, lse, (const float*)dP, dwV, (float*)dE12, dQ, dK, dV,
-                     dye_add, dye_mul, (int)bs, (int)n, scale, 7};   // every 8 rows: measured 2: 7.26, 4: 7.28, 8: 6.95, never: 8.17 ms per step
+                     dye_add, dye_mul, (int)bs, (int)n, scale, 7, 0};   // every 8 rows: measured 2: 7.26, 4: 7.28, 8: 6.95, never: 8.17 ms per step;
+                                                                    // meeting half a tile apart (stagger) costs 2 % here, gains 4 % in the forward
   if (const int sy = mbvae_opt(MBVAE_OPT_EFB_SYNC); sy > 0) a.sync_mask = sy - 1;
+  if (const int sg = mbvae_opt(MBVAE_OPT_EF_STAGGER); sg > 0) a.stagger = sg == 3 ? 0 : sg;
   const int grid = (int)std::min<int64_t>(bs, ef_num_cus());
   auto k = bf16 ? edge_fused_bwd_kernel<true> : edge_fused_bwd_kernel<false>;
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), sizeof(float) * 2 * 64 * 256, stream, a);
