@@ -327,9 +327,9 @@ struct EdgeFusedBwdArgs {
 template <bool BF16>
 __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a) {
   constexpr int SS = BF16 ? 2 : 4;                  // bytes per dP / dE1|dE2 element
-  // Register budget (256 per lane at 512 threads): the lane's W12 slice as three bf16 planes would take 96.  Its hi and
-  // mid planes therefore live in LDS - 16 bytes per (plane, octet, E1/E2, thread), written and read by their owner only,
-  // so no barrier guards them - and only the lo planes stay in registers.  K and V need no LDS here: with the key
+  // Register budget (256 per lane at 512 threads): the lane's W12 slice as three bf16 planes would take 96.  Most of
+  // them therefore live in LDS - 16 bytes per (plane, octet, E1/E2, thread), written and read by their owner only,
+  // so no barrier guards them.  K and V need no LDS here: with the key
   // tile as the outer loop a lane's 16 keys are fixed for a whole pass over the query rows and sit in registers.
   extern __shared__ __align__(16) float ef_kv[];
   mbvae_bf16x8* wl = reinterpret_cast<mbvae_bf16x8*>(ef_kv);      // [(plane * 4 + octet) * 2 + which][512]
@@ -340,7 +340,10 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
   const int n = a.n, ldq = a.ldq;
   const int RT = (n + 31) >> 5;
 
-  mbvae_bf16x8 l1[4], l2[4];                         // lo planes of the lane's E1 / E2 weight octets
+  // 20 of the 24 (plane, octet, E1/E2) slots fill the CU's whole 160 KB of LDS (this kernel has no static __shared__
+  // data): all hi and mid planes and four lo planes; the other four lo planes are registers.
+  constexpr int LO_LDS = 4;
+  mbvae_bf16x8 lo[8];                                // lo planes, slot = 2 * octet + (E2 ? 1 : 0); slots < LO_LDS live in LDS
   {
     const float* p1 = a.W + (int64_t)c * 64 + 32 * h;
     const float* p2 = a.W + (int64_t)(256 + c) * 64 + 32 * h;
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
       const MbvaeSplit3 s2 = mbvae_split8(v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w);
       wl[((0 * 4 + o) * 2 + 0) * 512 + tid] = s1.hi; wl[((0 * 4 + o) * 2 + 1) * 512 + tid] = s2.hi;
       wl[((1 * 4 + o) * 2 + 0) * 512 + tid] = s1.mid; wl[((1 * 4 + o) * 2 + 1) * 512 + tid] = s2.mid;
-      l1[o] = s1.lo; l2[o] = s2.lo;
+      if (2 * o < LO_LDS) wl[(16 + 2 * o) * 512 + tid] = s1.lo; else lo[2 * o] = s1.lo;
+      if (2 * o + 1 < LO_LDS) wl[(16 + 2 * o + 1) * 512 + tid] = s2.lo; else lo[2 * o + 1] = s2.lo;
     }
   }
   const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
@@ -384,6 +388,9 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
         const bool qi_ok = (kmask >> i) & 1ull;
         const int64_t qn = node + i;
         const float qv = a.Q[qn * ldq + c], ls = a.lse[qn * 256 + c], wv = a.wV[qn * 256 + c], dwv = a.dwV[qn * 256 + c];
+        // the first key tile's dQ partial (stored by this very lane) is requested here, a whole tile before it is added
+        float* const dqp = a.dQ + qn * ldq + c;
+        const float dq_prev = (mt > 0 && h == 0) ? *dqp : 0.f;
         // this tile's dP words are requested before the products and arrive underneath them
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char*>(const_cast<float*>(a.dP)) + qn * n * 256 * SS, 0, n * 256 * SS, 0x00020000);
@@ -409,14 +416,24 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
           ra[2 * o] = ef_ld4(nsrc + 8 * o); ra[2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);
           asm volatile("" : : : "memory");
           if (qi_ok && km32 != 0u) {                  // a tile without a valid pair needs no products (wave-uniform)
-            const mbvae_bf16x8 h1 = wl[((0 * 4 + o) * 2 + 0) * 512 + tid], h2 = wl[((0 * 4 + o) * 2 + 1) * 512 + tid];
-            const mbvae_bf16x8 m1 = wl[((1 * 4 + o) * 2 + 0) * 512 + tid], m2 = wl[((1 * 4 + o) * 2 + 1) * 512 + tid];
-            acc1 = MBVAE_MFMA_BF16(as.lo, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.lo, h2, acc2);
-            acc1 = MBVAE_MFMA_BF16(as.hi, l1[o], acc1); acc2 = MBVAE_MFMA_BF16(as.hi, l2[o], acc2);
-            acc1 = MBVAE_MFMA_BF16(as.mid, m1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, m2, acc2);
-            acc1 = MBVAE_MFMA_BF16(as.mid, h1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, h2, acc2);
-            acc1 = MBVAE_MFMA_BF16(as.hi, m1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, m2, acc2);
-            acc1 = MBVAE_MFMA_BF16(as.hi, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, h2, acc2);
+            // weight planes are fetched from LDS one pair at a time, in the order lo, mid, hi, each right before its
+            // products (8 registers in use at a time instead of 24); smaller terms still enter the sums first
+            {
+              const mbvae_bf16x8 w1l = 2 * o < LO_LDS ? wl[(16 + 2 * o) * 512 + tid] : lo[2 * o];
+              const mbvae_bf16x8 w2l = 2 * o + 1 < LO_LDS ? wl[(16 + 2 * o + 1) * 512 + tid] : lo[2 * o + 1];
+              acc1 = MBVAE_MFMA_BF16(as.hi, w1l, acc1);   acc2 = MBVAE_MFMA_BF16(as.hi, w2l, acc2);
+            }
+            {
+              const mbvae_bf16x8 m1 = wl[((1 * 4 + o) * 2 + 0) * 512 + tid], m2 = wl[((1 * 4 + o) * 2 + 1) * 512 + tid];
+              acc1 = MBVAE_MFMA_BF16(as.mid, m1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, m2, acc2);
+              acc1 = MBVAE_MFMA_BF16(as.hi, m1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, m2, acc2);
+            }
+            {
+              const mbvae_bf16x8 h1 = wl[((0 * 4 + o) * 2 + 0) * 512 + tid], h2 = wl[((0 * 4 + o) * 2 + 1) * 512 + tid];
+              acc1 = MBVAE_MFMA_BF16(as.lo, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.lo, h2, acc2);
+              acc1 = MBVAE_MFMA_BF16(as.mid, h1, acc1);   acc2 = MBVAE_MFMA_BF16(as.mid, h2, acc2);
+              acc1 = MBVAE_MFMA_BF16(as.hi, h1, acc1);    acc2 = MBVAE_MFMA_BF16(as.hi, h2, acc2);
+            }
           }
         }
         const bool meet = (i & a.sync_mask) == a.sync_mask;
@@ -451,10 +468,7 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
           dym += dp[v] * y;
         }
         dq += __shfl_xor(dq, 32);
-        if (h == 0) {
-          float* dst = a.dQ + qn * ldq + c;
-          *dst = mt == 0 ? dq : *dst + dq;           // the first key tile's sum was stored by this very lane
-        }
+        if (h == 0) *dqp = dq_prev + dq;
         if (meet && (a.stagger == 0 || grpB)) asm volatile("s_barrier" : : : "memory");   // keep the waves together: they share the E rows in L1
       }
 #pragma unroll
@@ -959,7 +973,19 @@ static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b1
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if (!mask || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
   if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
-  if (!(bf16 ? MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_fused_bwd_kernel<false>))) return MBVAE_ELAUNCH;
+  constexpr int kLds = 20 * 512 * 16;                // 20 thread-private 16-byte slots = the CU's whole 160 KB
+  {
+    static std::atomic<unsigned long long> done{0ull};   // per-device flag: the attribute is raised once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MBVAE_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+        return MBVAE_ELAUNCH;
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
   EdgeFusedBwdArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_mul, mask, wV, lse, (const float*)dP, dwV, (float*)dE12, dQ, dK, dV,
                      dye_add, dye_mul, (int)bs, (int)n, scale, 7, 0};   // every 8 rows: measured 2: 7.26, 4: 7.28, 8: 6.95, never: 8.17 ms per step;
                                                                     // meeting half a tile apart (stagger) costs 2 % here, gains 4 % in the forward
@@ -967,7 +993,7 @@ static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b1
   if (const int sg = mbvae_opt(MBVAE_OPT_EF_STAGGER); sg > 0) a.stagger = sg == 3 ? 0 : sg;
   const int grid = (int)std::min<int64_t>(bs, ef_num_cus());
   auto k = bf16 ? edge_fused_bwd_kernel<true> : edge_fused_bwd_kernel<false>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), sizeof(float) * 2 * 64 * 256, stream, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), kLds, stream, a);
   return mbvae_launch_status();
 }
 
