@@ -43,6 +43,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   extern __shared__ __align__(16) float ef_kv[];   // K rows [64][256], then V rows [64][256]
   float* Ks = ef_kv;
   float* Vs = ef_kv + 64 * 256;
+  constexpr int EF_LO_LDS = 3;                     // SPLIT: lo weight planes kept in LDS behind the K / V rows
+  mbvae_bf16x8* wlo = reinterpret_cast<mbvae_bf16x8*>(ef_kv + 2 * 64 * 256);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -68,6 +70,10 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       for (int o = 0; o < 4; ++o) {
         s1[o] = mbvae_split8(w1[8 * o], w1[8 * o + 1], w1[8 * o + 2], w1[8 * o + 3], w1[8 * o + 4], w1[8 * o + 5], w1[8 * o + 6], w1[8 * o + 7]);
         s2[o] = mbvae_split8(w2[8 * o], w2[8 * o + 1], w2[8 * o + 2], w2[8 * o + 3], w2[8 * o + 4], w2[8 * o + 5], w2[8 * o + 6], w2[8 * o + 7]);
+        // the LDS left over next to the K / V rows (24 KB) takes three of the eight lo planes (thread-private 16-byte
+        // slots, no barrier): 12 registers less, which is what keeps scratch reloads out of the tile loop
+        if (2 * o < EF_LO_LDS) wlo[(2 * o) * 512 + tid] = s1[o].lo;
+        if (2 * o + 1 < EF_LO_LDS) wlo[(2 * o + 1) * 512 + tid] = s2[o].lo;
       }
     }
   }
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
           ra[0][2 * o] = ef_ld4(nsrc + 8 * o); ra[0][2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);            \
           asm volatile("" : : : "memory");                                                             \
           acc1 = MBVAE_MFMA_BF16(as.lo, s1[o].hi, acc1);   acc2 = MBVAE_MFMA_BF16(as.lo, s2[o].hi, acc2);   \
-          acc1 = MBVAE_MFMA_BF16(as.hi, s1[o].lo, acc1);   acc2 = MBVAE_MFMA_BF16(as.hi, s2[o].lo, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(as.hi, 2 * o < EF_LO_LDS ? wlo[(2 * o) * 512 + tid] : s1[o].lo, acc1);    \
+          acc2 = MBVAE_MFMA_BF16(as.hi, 2 * o + 1 < EF_LO_LDS ? wlo[(2 * o + 1) * 512 + tid] : s2[o].lo, acc2); \
           acc1 = MBVAE_MFMA_BF16(as.mid, s1[o].mid, acc1); acc2 = MBVAE_MFMA_BF16(as.mid, s2[o].mid, acc2); \
           acc1 = MBVAE_MFMA_BF16(as.mid, s1[o].hi, acc1);  acc2 = MBVAE_MFMA_BF16(as.mid, s2[o].hi, acc2);  \
           acc1 = MBVAE_MFMA_BF16(as.hi, s1[o].mid, acc1);  acc2 = MBVAE_MFMA_BF16(as.hi, s2[o].mid, acc2);  \
@@ -902,7 +909,7 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
   EdgeFusedArgs a{E, W12, b12, Q, K, V, (int)ldq, ye_add, ye_mul, mask, P, wV, lse, E12, (int)bs, (int)n, scale, ichunks,
                   work_counter, node_off, graph_order, 1};
   if (const int sg = mbvae_opt(MBVAE_OPT_EF_STAGGER); sg > 0) a.stagger = sg == 3 ? 0 : sg;
-  const size_t smem = sizeof(float) * 2 * 64 * 256;
+  const size_t smem = sizeof(float) * 2 * 64 * 256 + 3 * 512 * 16;    // K, V rows + three thread-private weight-plane slots
   const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
   const bool wr = E12 != nullptr || train_form;    // training form: P (and E1|E2 when given) for every pair
   void (*k)(EdgeFusedArgs);
