@@ -260,6 +260,23 @@ def main():
                     num += wgt * v["mfma_busy_frac"]; den += wgt
             if den > 0:
                 roofline["mfma_busy_frac"] = round(num / den, 4)
+        # the same products on the native fp32 MFMA kernels (NO_SPLIT_MFMA route, earlier counter pass): busy fractions there
+        fpath = os.path.join(ROOT, "profiles", "mfma_busy_fp32_mfma_kernels.json")
+        if os.path.exists(fpath):
+            with open(fpath) as f:
+                vals = [v["mfma_busy_frac"] for k, v in json.load(f).items()
+                        if k.startswith("mbvae_linear") and isinstance(v, dict) and v.get("mfma_busy_frac", 0) > 0]
+            if vals:
+                roofline["mfma_busy_frac_native_fp32_kernels"] = round(sum(vals) / len(vals), 4)
+        # edge-path projections alone ([bs*n*n, d] rows): fp32-equivalent rate, also as a fraction of the fp32 MFMA peak
+        e_ms = e_fl = 0.0
+        for (nm, tg), evs in profile.items():
+            if nm.startswith("mbvae_linear") and tg is not None and tg[0] == bs * n * n and min(tg[1], tg[2]) >= 64:
+                e_ms += sum(a.elapsed_time(b) for a, b in evs)
+                e_fl += 2.0 * tg[0] * tg[1] * tg[2] * len(evs)
+        if e_ms > 0:
+            roofline["edge_projections_TFLOPs"] = round(e_fl / e_ms / 1e9, 2)
+            roofline["edge_projections_frac_of_fp32_mfma_peak"] = round(e_fl / e_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)
         for nm in ea_bytes:
             r = rows.get(nm)
             if r and r["ms"] > 0:

@@ -101,8 +101,16 @@ with torch.enable_grad():
     y.backward(dy)
     mark("mbvae_pool_stats_fwd:E")
     s = ops.pool_stats(x)
+    # the backward entry point on its own, accumulating into an existing gradient as it does in the denoiser step
+    # (through autograd the segment would also hold torch's gradient-accumulation kernel)
+    from mbvae_amd import _lib as _l
+    stats = torch.empty(bs, 4 * de, device=dev); arg = torch.empty(bs, 2, de, dtype=torch.int32, device=dev)
+    _l.call("mbvae_pool_stats_fwd", x.data_ptr(), stats.data_ptr(), arg.data_ptr(), bs, n * n, de, torch.cuda.current_stream().cuda_stream)
+    dxp = torch.randn_like(x)
+    torch.cuda.synchronize()
     mark("mbvae_pool_stats_bwd:E")
-    s.backward(ds)
+    _l.call("mbvae_pool_stats_bwd", x.data_ptr(), stats.data_ptr(), arg.data_ptr(), ds.data_ptr(), dxp.data_ptr(), bs, n * n, de, 1,
+            torch.cuda.current_stream().cuda_stream)
     mark("end")
 torch.cuda.synchronize()
 out = os.environ.get("TRAFFIC_MANIFEST")
