@@ -345,3 +345,55 @@ def test_conditional_generator_latent_optimisation_golden():
     # the latents themselves (O(1) values moved by <= 12 * lr) agree to 1e-5 of their scale
     assert_close(best, g["best"], what="optimised latents")
     assert meta[:, 0].tolist() == [0, 0, 0, 1, 1, 1] and meta[:, 1].tolist() == [0, 1, 2, 0, 1, 2]
+
+
+def test_encoder_train_step_replays_from_one_hip_graph():
+    """The library's entry points only launch kernels on the current stream (no allocation, no synchronisation), so a
+    whole encoder train step - forward, backward, optimiser - can be captured in ONE HIP graph.  Three replays must leave
+    the weights that three eager steps leave (dropout off).  Plain SGD on purpose: Adam divides by the gradient's own
+    magnitude, which turns the rounding noise of gradients that are zero in exact arithmetic (the attention-logit bias
+    under softmax) into updates of +-lr and would make any comparison of those entries meaningless."""
+    g = load_golden("variants")
+    base = _variant("multi_output")
+    base.load_state_dict(g["multi_output_sd"], strict=True)
+    feat_d, feat_t = g["feat_d"]["FP-Morgan"].cuda(), g["feat_t"]["FP-ESP"].cuda()      # the single-view model's inputs
+    target = g["y"]["Y_pKd"].cuda()
+    mask = g["y"]["Y_pKd_mask"].bool().cuda().float()
+
+    def step(model, opt):
+        emb, pred = model(feat_d, feat_t)
+        loss = (((pred.dti_scores["Y_pKd"] - target) ** 2) * mask).sum() / mask.sum().clamp(min=1.0)   # static shapes
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def make():
+        m = _variant("multi_output")
+        m.load_state_dict(g["multi_output_sd"], strict=True)
+        m = m.cuda().eval()
+        return m, torch.optim.SGD(m.parameters(), lr=0.05)
+
+    eager, opt_e = make()
+    for _ in range(3):
+        opt_e.zero_grad(set_to_none=True)
+        step(eager, opt_e)
+    captured, opt_c = make()
+    # (the usual warm-up before capture would already move the weights; every lazily created buffer of this path -
+    #  workspace, option tables, kernel attributes - was created by the eager model above)
+    graph = torch.cuda.CUDAGraph()
+    opt_c.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        loss = step(captured, opt_c)
+    # capture does not execute: nothing has changed yet
+    for (k, a), (_, b) in zip(captured.state_dict().items(), base.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    moved = 0.0
+    for (k, a), (_, b), (_, c) in zip(captured.state_dict().items(), eager.state_dict().items(), base.state_dict().items()):
+        assert_close(a, b, atol=1e-6 if _is_null_grad(k) else None, what=k + " (graph replays vs eager steps)")
+        moved = max(moved, float((b.cpu() - c).abs().max()))
+    assert moved > 1e-3, "the steps did not train anything"
