@@ -26,6 +26,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def default_routes():
+    """Tests that assert WHICH entry points ran pin the library's route switches to their defaults (the suite may be
+    run with MBVAE_NO_SPLIT_MFMA / MBVAE_NO_E12_RECOMPUTE in the environment to exercise the other routes)."""
+    from mbvae_amd import _lib
+    with _lib.option("NO_SPLIT_MFMA", 0), _lib.option("NO_E12_RECOMPUTE", 0):
+        yield
+
+
 def _ragged(bs, n, g):
     sizes = torch.randint(n // 2, n + 1, (bs,), generator=g)
     sizes[0] = n
@@ -112,7 +121,7 @@ def _layer_run(ops, bf16, seed=0):
     return dict(oX=oX.detach(), oE=oE.detach(), oy=oy.detach(), dX=X.grad, dE=E.grad, dy=y.grad, **grads), called
 
 
-def test_bf16_storage_layer_matches_fp32_within_2e_2(ops):
+def test_bf16_storage_layer_matches_fp32_within_2e_2(ops, default_routes):
     ref, called_ref = _layer_run(ops, False)
     got, called = _layer_run(ops, True)
     # the mode really ran on the bf16 entry points (and the default really did not)
@@ -160,7 +169,7 @@ def test_bf16_storage_train_steps_track_fp32(ops):
         assert math.isfinite(b) and abs(a - b) <= BF16_RTOL * abs(a), (losses[False], losses[True])
 
 
-def test_bf16_recomputing_pair_matches_fp32_edge_block(ops):
+def test_bf16_recomputing_pair_matches_fp32_edge_block(ops, default_routes):
     """Batches of at least one graph per two compute units take the recomputing pair in bf16 mode as well (P, dP and
     dE1|dE2 in bf16, E1|E2 never stored): forward element-wise and gradients in relative L2 within 2e-2 of fp32."""
     from mbvae_amd import _lib

@@ -24,6 +24,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def default_routes():
+    """Tests that assert WHICH entry points ran pin the library's route switches to their defaults (the suite may be
+    run with MBVAE_NO_SPLIT_MFMA / MBVAE_NO_E12_RECOMPUTE in the environment to exercise the other routes)."""
+    from mbvae_amd import _lib
+    with _lib.option("NO_SPLIT_MFMA", 0), _lib.option("NO_E12_RECOMPUTE", 0):
+        yield
+
+
 def dev(t):
     return t.cuda() if torch.is_tensor(t) else t
 
@@ -843,7 +852,7 @@ def test_edge_block_fused_forward(ops, bs, n, sizes, monkeypatch):
 
 
 @pytest.mark.parametrize("bs,n,ragged", [(128, 64, True), (160, 16, False), (130, 33, True), (128, 40, True)])
-def test_edge_block_recompute_backward(ops, bs, n, ragged):
+def test_edge_block_recompute_backward(ops, bs, n, ragged, default_routes):
     """Batches of at least one graph per two compute units train through the pair that never stores E1|E2: the forward
     writes P / wV / lse only and the backward forms the projection again from E.  Values and all gradients against the
     plain torch restatement; bitwise equal from run to run; and the storing pair gives the same numbers."""
