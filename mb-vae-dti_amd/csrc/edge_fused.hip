@@ -501,6 +501,31 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
 // lane holds 32 of its row's 64 outputs and lane + 32 the others: residual add and LayerNorm are register
 // arithmetic plus one cross-half exchange per statistic.  Per row 256 B are read and 256 B written; the separate
 // kernels move 2.3 KB.
+// helpers of the bf16-pipeline forms below
+typedef unsigned ef_u32x2 __attribute__((ext_vector_type(2)));
+// one fp32 weight -> its three bf16 planes, `plane` elements apart
+__device__ __forceinline__ void ef_store_planes(unsigned short* dst, int plane, float w) {
+  const unsigned u = __float_as_uint(w);
+  const float r1 = w - __uint_as_float(u & 0xffff0000u);
+  const unsigned v = __float_as_uint(r1);
+  const float r2 = r1 - __uint_as_float(v & 0xffff0000u);
+  dst[0] = (unsigned short)(u >> 16); dst[plane] = (unsigned short)(v >> 16); dst[2 * plane] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+// eight consecutive bf16 (16-byte aligned) / two runs of four, eight elements apart (8-byte aligned each)
+__device__ __forceinline__ mbvae_bf16x8 ef_ld8(const unsigned short* p) { return *reinterpret_cast<const mbvae_bf16x8*>(p); }
+__device__ __forceinline__ mbvae_bf16x8 ef_ld44(const unsigned short* p) {
+  const ef_u32x2 a = *reinterpret_cast<const ef_u32x2*>(p), b = *reinterpret_cast<const ef_u32x2*>(p + 8);
+  mbvae_u32x4 v; v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  return __builtin_bit_cast(mbvae_bf16x8, v);
+}
+// acc += W (A operand: planes wh, wm, wl) x activations (B operand: split xs), smaller terms first
+#define EF_SPLIT_MFMA(acc, wh, wm, wl, xs)                                                              \
+  {                                                                                                     \
+    const mbvae_bf16x8 wh_ = (wh), wm_ = (wm), wl_ = (wl);                                              \
+    acc = MBVAE_MFMA_BF16(wl_, xs.hi, acc); acc = MBVAE_MFMA_BF16(wh_, xs.lo, acc); acc = MBVAE_MFMA_BF16(wm_, xs.mid, acc); \
+    acc = MBVAE_MFMA_BF16(wm_, xs.hi, acc); acc = MBVAE_MFMA_BF16(wh_, xs.mid, acc); acc = MBVAE_MFMA_BF16(wh_, xs.hi, acc); \
+  }
+
 struct EdgeFfnArgs {
   const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
   const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
@@ -567,12 +592,20 @@ struct EfTileWindow {
   }
 };
 
+// SPLIT: both products on the bf16 matrix pipeline (six bf16 MFMAs per fp32 product, see mbvae_split8).  The weights
+// are split once, at staging time, into three bf16 planes per matrix, rows padded by 16 bytes so that the A-operand
+// fetches are conflict-free; the activations (x rows, then the ReLU'd hidden accumulators - eight consecutive
+// accumulator registers ARE one B-operand octet) are split in registers, once per 16 reduction indices.
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   constexpr int L1 = 65, L2 = 129;                  // LDS row strides of W1 [128][64] and W2 [64][128]
+  constexpr int K1 = 72, K2 = 136;                  // SPLIT: bf16 elements per row of the W1 / W2 planes
   extern __shared__ __align__(16) float ff_lds[];
   float* W1s = ff_lds;                              // [128][L1]
   float* W2s = W1s + 128 * L1;                      // [64][L2]
-  float* b1s = W2s + 64 * L2;                       // [128]
+  unsigned short* W1p = reinterpret_cast<unsigned short*>(ff_lds);     // SPLIT: [3][128][K1]
+  unsigned short* W2p = W1p + 3 * 128 * K1;                            // SPLIT: [3][64][K2]
+  float* b1s = SPLIT ? reinterpret_cast<float*>(W2p + 3 * 64 * K2) : W2s + 64 * L2;   // [128]
   float* b2s = b1s + 128;                           // [64]
   float* gs = b2s + 64;                             // [64]
   float* bs_ = gs + 64;                             // [64]
@@ -580,7 +613,14 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 128 * 64; e += 512) { W1s[(e >> 6) * L1 + (e & 63)] = a.W1[e]; W2s[(e >> 7) * L2 + (e & 127)] = a.W2[e]; }
+  if (SPLIT) {
+    for (int e = tid; e < 128 * 64; e += 512) {
+      ef_store_planes(W1p + (e >> 6) * K1 + (e & 63), 128 * K1, a.W1[e]);
+      ef_store_planes(W2p + (e >> 7) * K2 + (e & 127), 64 * K2, a.W2[e]);
+    }
+  } else {
+    for (int e = tid; e < 128 * 64; e += 512) { W1s[(e >> 6) * L1 + (e & 63)] = a.W1[e]; W2s[(e >> 7) * L2 + (e & 127)] = a.W2[e]; }
+  }
   if (tid < 128) b1s[tid] = a.b1 ? a.b1[tid] : 0.f;
   if (tid < 64) { b2s[tid] = a.b2 ? a.b2[tid] : 0.f; gs[tid] = a.gamma[tid]; bs_[tid] = a.beta[tid]; }
   __syncthreads();
@@ -641,6 +681,17 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     f32x16 hh[4];                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) hh[t][v] = b1s[32 * t + h4 + (v & 3) + 8 * (v >> 2)]; \
+    if (SPLIT) {                                                                                       \
+      _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                  \
+        float4 t4 = ra[S][2 * o], u4 = ra[S][2 * o + 1];                                               \
+        asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory"); \
+        const MbvaeSplit3 xs = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);           \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+          const unsigned short* wp = W1p + (32 * t + r) * K1 + 32 * h + 8 * o + oz;   /* W1[unit r + 32t][k octet] */ \
+          EF_SPLIT_MFMA(hh[t], ef_ld8(wp), ef_ld8(wp + 128 * K1), ef_ld8(wp + 2 * 128 * K1), xs)       \
+        }                                                                                              \
+      }                                                                                                \
+    } else {                                                                                           \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
       float4 t4 = ra[S][p];                                                                            \
       asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
@@ -651,10 +702,24 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
           hh[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * t * L1], xs[e], hh[t], 0, 0, 0);      \
       }                                                                                                \
     }                                                                                                  \
+    }                                                                                                  \
     /* output layer: the (ReLU'd) hidden registers are the B operand */                                \
     f32x16 yy[2];                                                                                      \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = b2s[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
+    if (SPLIT) {                                                                                       \
+      /* accumulator registers 8g .. 8g+7 of hidden tile t hold units 32t + 16g + 4h + {0..3, 8..11}: one octet */ \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                             \
+          const MbvaeSplit3 hs = mbvae_split8(fmaxf(hh[t][8 * gp], 0.f), fmaxf(hh[t][8 * gp + 1], 0.f), fmaxf(hh[t][8 * gp + 2], 0.f), \
+                                              fmaxf(hh[t][8 * gp + 3], 0.f), fmaxf(hh[t][8 * gp + 4], 0.f), fmaxf(hh[t][8 * gp + 5], 0.f), \
+                                              fmaxf(hh[t][8 * gp + 6], 0.f), fmaxf(hh[t][8 * gp + 7], 0.f)); \
+          _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const unsigned short* wp = W2p + (32 * u + r) * K2 + 32 * t + 16 * gp + h4;                \
+            EF_SPLIT_MFMA(yy[u], ef_ld44(wp), ef_ld44(wp + 64 * K2), ef_ld44(wp + 2 * 64 * K2), hs)    \
+          }                                                                                            \
+        }                                                                                              \
+    } else {                                                                                           \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                                 \
         const float hv = fmaxf(hh[t][v], 0.f);                                                         \
@@ -662,6 +727,7 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
         yy[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[0], hv, yy[0], 0, 0, 0);                     \
         yy[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[32 * L2], hv, yy[1], 0, 0, 0);               \
       }                                                                                                \
+    }                                                                                                  \
     }                                                                                                  \
     /* residual + LayerNorm: this lane has columns 32u + 8g + 4h + (0..3) of row `tile*32 + r` */      \
     const bool inb = sinb[S];                                                                          \
@@ -718,18 +784,22 @@ struct EdgeOutArgs {
   int uniform;     // the padding rows of E all hold the same values: one is evaluated per wave, the rest only stored
 };
 
+template <bool SPLIT>                               // SPLIT: the product on the bf16 matrix pipeline (see edge_ffn_fwd_kernel)
 __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
   constexpr int LW = 257;                           // LDS row stride of W [64][256]
+  constexpr int KW = 264;                           // SPLIT: bf16 elements per row of the W planes
   extern __shared__ __align__(16) float eo_lds[];
   float* Ws = eo_lds;                               // [64][LW]
-  float* bsv = Ws + 64 * LW;                        // [64]
+  unsigned short* Wp = reinterpret_cast<unsigned short*>(eo_lds);      // SPLIT: [3][64][KW]
+  float* bsv = SPLIT ? reinterpret_cast<float*>(Wp + 3 * 64 * KW) : Ws + 64 * LW;   // [64]
   float* gs = bsv + 64;
   float* bt_ = gs + 64;
   float* cst = bt_ + 64;                            // [8][64]: per wave, the output row shared by all padding rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 64 * 256; e += 512) Ws[(e >> 8) * LW + (e & 255)] = a.W[e];
+  if (SPLIT) { for (int e = tid; e < 64 * 256; e += 512) ef_store_planes(Wp + (e >> 8) * KW + (e & 255), 64 * KW, a.W[e]); }
+  else { for (int e = tid; e < 64 * 256; e += 512) Ws[(e >> 8) * LW + (e & 255)] = a.W[e]; }
   if (tid < 64) { bsv[tid] = a.b ? a.b[tid] : 0.f; gs[tid] = a.gamma[tid]; bt_[tid] = a.beta[tid]; }
   __syncthreads();
 
@@ -801,7 +871,17 @@ __global__ __launch_bounds__(512) void edge_out_ln_fwd_kernel(EdgeOutArgs a) {
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) yy[u][v] = bsv[32 * u + h4 + (v & 3) + 8 * (v >> 2)]; \
     }                                                                                                  \
-    if (mode[S] == 0)                                                                                  \
+    if (SPLIT && mode[S] == 0) {                                                                       \
+      _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                  \
+        float4 t4 = ra[S][2 * o], u4 = ra[S][2 * o + 1];                                               \
+        asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory"); \
+        const MbvaeSplit3 xs = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);           \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                \
+          const unsigned short* wp = Wp + (32 * u + r) * KW + gi * 64 + 32 * h + 8 * o + oz;           \
+          EF_SPLIT_MFMA(yy[u], ef_ld8(wp), ef_ld8(wp + 64 * KW), ef_ld8(wp + 2 * 64 * KW), xs)         \
+        }                                                                                              \
+      }                                                                                                \
+    } else if (mode[S] == 0)                                                                           \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                    \
       float4 t4 = ra[S][p];                                                                            \
       asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w) : : "memory");                  \
@@ -1045,10 +1125,12 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
   EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid};
-  const size_t smem = sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
-  if (!MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel)) return MBVAE_ELAUNCH;
+  const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+  const size_t smem = split ? 2 * 3 * (128 * 72 + 64 * 136) + sizeof(float) * (128 + 3 * 64 + 8 * 64)
+                            : sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
+  if (!(split ? MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel<false>))) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
-  hipLaunchKernelGGL(edge_ffn_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL(split ? edge_ffn_fwd_kernel<true> : edge_ffn_fwd_kernel<false>, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 
@@ -1066,10 +1148,11 @@ int mbvae_edge_out_ln_fwd(const float* P, const float* W, const float* b, const 
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
   EdgeOutArgs a{P, W, b, E, mask, (int)n, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid, uniform_padding};
-  const size_t smem = sizeof(float) * (64 * 257 + 3 * 64 + 8 * 64);
-  if (!MBVAE_ALLOW_BIG_LDS(edge_out_ln_fwd_kernel)) return MBVAE_ELAUNCH;
+  const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+  const size_t smem = split ? 2 * 3 * 64 * 264 + sizeof(float) * (3 * 64 + 8 * 64) : sizeof(float) * (64 * 257 + 3 * 64 + 8 * 64);
+  if (!(split ? MBVAE_ALLOW_BIG_LDS(edge_out_ln_fwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_out_ln_fwd_kernel<false>))) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
-  hipLaunchKernelGGL(edge_out_ln_fwd_kernel, dim3(grid), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL(split ? edge_out_ln_fwd_kernel<true> : edge_out_ln_fwd_kernel<false>, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 
