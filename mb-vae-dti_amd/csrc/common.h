@@ -41,13 +41,15 @@ enum MbvaeOption {
   MBVAE_OPT_NO_E12_RECOMPUTE,   // training: store the e_mul|e_add projection output in the forward instead of recomputing it in the backward
   MBVAE_OPT_EFB_SYNC,      // recomputing edge backward: waves meet every (value) query rows, a power of two; 0 = default (8)
   MBVAE_OPT_EF_STAGGER,    // fused edge kernels, training forms: 0 = default (forward 1, backward in phase); 1 = waves 0-3 / 4-7 meet half a tile apart; 2 = even / odd waves; 3 = all in phase
+  MBVAE_OPT_NO_COLGROUPS,  // node-path Linear shapes on the generic LDS-tiled kernel instead of column groups of the tall-skinny one
+  MBVAE_OPT_NO_EF_COOP,    // fused edge forward: every wave fetches and splits the whole operand tile itself (no shared planes in LDS)
   MBVAE_OPT_COUNT
 };
 inline const char* const* mbvae_option_names() {
   static const char* const names[MBVAE_OPT_COUNT] = {"NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64", "NO_TSWGRAD", "NO_TSWGRAD2",
                                                      "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
                                                      "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE", "NO_SPLIT_MFMA",
-                                                     "NO_E12_RECOMPUTE", "EFB_SYNC", "EF_STAGGER"};
+                                                     "NO_E12_RECOMPUTE", "EFB_SYNC", "EF_STAGGER", "NO_COLGROUPS", "NO_EF_COOP"};
   return names;
 }
 struct MbvaeOptions {
@@ -58,7 +60,8 @@ struct MbvaeOptions {
       snprintf(name, sizeof(name), "MBVAE_%s", mbvae_option_names()[i]);
       const char* e = getenv(name);
       int val = i == MBVAE_OPT_GEMM_TILE ? -1 : 0;
-      if (e) val = (i == MBVAE_OPT_GEMM_TILE || i == MBVAE_OPT_EA_KEYS || i == MBVAE_OPT_EFB_SYNC || i == MBVAE_OPT_EF_STAGGER) ? (*e ? atoi(e) : (i == MBVAE_OPT_GEMM_TILE ? -1 : 0)) : 1;
+      // "MBVAE_X=<number>" sets the number (so "=0" switches a flag OFF); set but empty or non-numeric means 1
+      if (e) val = (*e == '-' || (*e >= '0' && *e <= '9')) ? atoi(e) : 1;
       v[i].store(val, std::memory_order_relaxed);
     }
   }

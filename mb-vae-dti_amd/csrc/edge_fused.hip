@@ -17,6 +17,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned ef_u32x2 __attribute__((ext_vector_type(2)));
 
 struct EdgeFusedArgs {
   const float* E; const float* W; const float* bias;
@@ -37,14 +38,22 @@ __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_c
 // registers right before their products, one split per 16 reduction indices shared by the E1 and the E2 tile.
 // BF16OUT: P and E1|E2 are stored as bf16 (round to nearest even) - the opt-in reduced-precision storage mode; the
 // softmax statistics and wV are computed from the unrounded fp32 values.
-template <bool WRITE_E12, bool SPLIT, bool BF16OUT = false>
+// COOP (with SPLIT): the eight waves of the workgroup multiply the SAME E rows by different weight slices, so splitting
+// those rows in every wave does the work eight times.  Instead each wave fetches and splits one eighth of the next tile
+// (one 16-byte load and 22 vector instructions per lane instead of eight loads and 176) and parks the planes in the
+// 24 KB of LDS next to the K / V rows (two tile buffers, 16-byte groups XOR-swizzled by row: the A-operand fetch of
+// the products - lane (key, half) reads eight consecutive reduction indices - is then free of bank conflicts); one
+// barrier per tile hands the buffer over.  The operand double buffer in registers (32) shrinks to one float4.
+template <bool WRITE_E12, bool SPLIT, bool BF16OUT = false, bool COOP = false>
 __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
+  static_assert(!COOP || SPLIT, "the shared operand planes are bf16 planes");
   constexpr int OS = BF16OUT ? 2 : 4;              // bytes per stored P / E1|E2 element
   extern __shared__ __align__(16) float ef_kv[];   // K rows [64][256], then V rows [64][256]
   float* Ks = ef_kv;
   float* Vs = ef_kv + 64 * 256;
   constexpr int EF_LO_LDS = 3;                     // SPLIT: lo weight planes kept in LDS behind the K / V rows
   mbvae_bf16x8* wlo = reinterpret_cast<mbvae_bf16x8*>(ef_kv + 2 * 64 * 256);
+  unsigned char* Ap = reinterpret_cast<unsigned char*>(ef_kv + 2 * 64 * 256);   // COOP: [2 buffers][3 planes][32 keys][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -72,8 +81,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
         s2[o] = mbvae_split8(w2[8 * o], w2[8 * o + 1], w2[8 * o + 2], w2[8 * o + 3], w2[8 * o + 4], w2[8 * o + 5], w2[8 * o + 6], w2[8 * o + 7]);
         // the LDS left over next to the K / V rows (24 KB) takes three of the eight lo planes (thread-private 16-byte
         // slots, no barrier): 12 registers less, which is what keeps scratch reloads out of the tile loop
-        if (2 * o < EF_LO_LDS) wlo[(2 * o) * 512 + tid] = s1[o].lo;
-        if (2 * o + 1 < EF_LO_LDS) wlo[(2 * o + 1) * 512 + tid] = s2[o].lo;
+        if (!COOP && 2 * o < EF_LO_LDS) wlo[(2 * o) * 512 + tid] = s1[o].lo;     // (COOP: that LDS holds the operand planes,
+        if (!COOP && 2 * o + 1 < EF_LO_LDS) wlo[(2 * o + 1) * 512 + tid] = s2[o].lo;   //  and the registers it frees hold these)
       }
     }
   }
@@ -86,7 +95,11 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
   // for the two groups - after the products for group A, after the epilogue for group B - which keeps the groups half
   // a tile apart: while one multiplies the other runs its epilogue.  Same number of barriers per tile for every wave.
   const bool grpB = a.stagger == 1 ? wave >= 4 : (a.stagger == 2 ? (wave & 1) != 0 : false);
-  const bool stag = WRITE_E12 && a.stagger != 0;
+  const bool stag = WRITE_E12 && !COOP && a.stagger != 0;
+  // COOP: this lane's share of a tile is 4 reduction indices of one key
+  const int prow_ = 4 * wave + (lane >> 4), pk4 = (lane & 15) * 4;
+  const int pst = prow_ * 128 + (((pk4 >> 3) ^ (prow_ & 7)) << 4) + ((pk4 >> 2) & 1) * 8;   // byte offset inside a plane
+  float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 ra[2][8];
   float qv[2];
@@ -151,6 +164,31 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       qv[S] = a.Q[(pnode + i0 + ii) * ldq + c];                                                        \
       asm volatile("" : : : "memory");       /* issue the loads here, do not sink them to their use */ \
     }
+    /* COOP: this lane's 16 bytes of tile t; its three planes into buffer `buf` */                   \
+#define EF_PIECE(t)                                                                                   \
+    ([&]() -> float4 {                                                                                \
+      const int tt = min((t), T - 1);                                                                  \
+      const int ii = RTq == 2 ? tt >> 1 : tt, mt = RTq == 2 ? tt & 1 : 0;                              \
+      return ef_ld4(a.E + (((node + i0 + ii) * n + min(32 * mt + prow_, n - 1)) * 64 + pk4));          \
+    }())
+#define EF_STAGE(buf, v4)                                                                             \
+    {                                                                                                 \
+      ef_u32x2 ph, pm, pl;                                                                             \
+      const float xv[4] = {(v4).x, (v4).y, (v4).z, (v4).w};                                            \
+      _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                               \
+        const float a0 = xv[2 * p2], a1 = xv[2 * p2 + 1];                                              \
+        const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);                             \
+        ph[p2] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                                           \
+        const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u); \
+        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);                             \
+        pm[p2] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);                                           \
+        const float q0 = r0 - __uint_as_float(v0 & 0xffff0000u), q1 = r1 - __uint_as_float(v1 & 0xffff0000u); \
+        pl[p2] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);         \
+      }                                                                                                \
+      unsigned char* dst = Ap + (buf) * 12288 + pst;                                                   \
+      *reinterpret_cast<ef_u32x2*>(dst) = ph; *reinterpret_cast<ef_u32x2*>(dst + 4096) = pm;           \
+      *reinterpret_cast<ef_u32x2*>(dst + 8192) = pl;                                                   \
+    }
 #define EF_ST(ptr_rsrc, val, voff, soff)                                                             \
     do {                                                                                              \
       if (BF16OUT) __builtin_amdgcn_raw_buffer_store_b16(mbvae_f2bf(val), ptr_rsrc, voff, (soff) / 2, 2); \
@@ -163,11 +201,32 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
       const bool qi_ok = (kmask >> i) & 1ull;                                                          \
       const unsigned km32 = (unsigned)(kmask >> (32 * mt));                                            \
       if (mt == 0) { m_run = -INFINITY; l_run = 0.f; av_run = 0.f; }                                   \
-      if (SPLIT && !(qi_ok && km32 != 0u)) EF_FETCH((t) + 1, 1 - S)   /* no products here: request the next tile whole */ \
+      if (SPLIT && !COOP && !(qi_ok && km32 != 0u)) EF_FETCH((t) + 1, 1 - S)   /* no products here: request the next tile whole */ \
+      if (COOP) {                                  /* hand tile t+1 to buffer 1-S, request this lane's share of tile t+2 */ \
+        const int tn = min((t) + 1, T - 1);                                                            \
+        qv[1 - S] = a.Q[(pnode + i0 + (RTq == 2 ? tn >> 1 : tn)) * ldq + c];                           \
+        EF_STAGE(1 - S, nx)                                                                            \
+        nx = EF_PIECE((t) + 2);                                                                        \
+        asm volatile("" : : : "memory");                                                               \
+      }                                                                                                \
       if (WRITE_E12 || (qi_ok && km32 != 0u)) {    /* inference: a tile without a valid pair is skipped */ \
       f32x16 acc1, acc2;                                                                               \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }                   \
-      if (SPLIT && qi_ok && km32 != 0u) {                                                              \
+      if (COOP && qi_ok && km32 != 0u) {                                                               \
+        const unsigned char* Ab = Ap + S * 12288 + r * 128;                                            \
+        _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                \
+          const int sw = ((4 * h + o) ^ (r & 7)) << 4;                                                 \
+          const mbvae_bf16x8 ahi = *reinterpret_cast<const mbvae_bf16x8*>(Ab + sw);                    \
+          const mbvae_bf16x8 ami = *reinterpret_cast<const mbvae_bf16x8*>(Ab + 4096 + sw);             \
+          const mbvae_bf16x8 alo = *reinterpret_cast<const mbvae_bf16x8*>(Ab + 8192 + sw);             \
+          acc1 = MBVAE_MFMA_BF16(alo, s1[o].hi, acc1);  acc2 = MBVAE_MFMA_BF16(alo, s2[o].hi, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(ahi, s1[o].lo, acc1);  acc2 = MBVAE_MFMA_BF16(ahi, s2[o].lo, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(ami, s1[o].mid, acc1); acc2 = MBVAE_MFMA_BF16(ami, s2[o].mid, acc2);  \
+          acc1 = MBVAE_MFMA_BF16(ami, s1[o].hi, acc1);  acc2 = MBVAE_MFMA_BF16(ami, s2[o].hi, acc2);   \
+          acc1 = MBVAE_MFMA_BF16(ahi, s1[o].mid, acc1); acc2 = MBVAE_MFMA_BF16(ahi, s2[o].mid, acc2);  \
+          acc1 = MBVAE_MFMA_BF16(ahi, s1[o].hi, acc1);  acc2 = MBVAE_MFMA_BF16(ahi, s2[o].hi, acc2);   \
+        }                                                                                              \
+      } else if (SPLIT && qi_ok && km32 != 0u) {                                                       \
         /* ONE operand buffer: an octet is dead once split, so the next tile's octet is requested into the same     \
            registers right there and has the rest of this tile (products, softmax, stores) to arrive */              \
         const int tn = min((t) + 1, T - 1);                                                            \
@@ -286,9 +345,18 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
         if (h == 0) { a.wV[(pnode + i) * 256 + c] = o; a.lse[(pnode + i) * 256 + c] = s; }             \
       }                                                                                                \
       if (stag && grpB) asm volatile("s_barrier" : : : "memory");                                      \
+      if (COOP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");   /* buffer 1-S is complete, buffer S is free */ \
     }
 
-    EF_FETCH(0, 0)
+    if (COOP) {                                      // tile 0 into buffer 0, this lane's share of tile 1 on its way
+      qv[0] = a.Q[(pnode + i0) * ldq + c];
+      nx = EF_PIECE(0);
+      EF_STAGE(0, nx)
+      nx = EF_PIECE(1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    } else {
+      EF_FETCH(0, 0)
+    }
     for (int t = 0; t < T; t += 2) {
       if (!SPLIT) EF_FETCH(t + 1, 1)
       EF_TILE(t, 0)
@@ -303,6 +371,8 @@ __global__ __launch_bounds__(512) void edge_fused_fwd_kernel(EdgeFusedArgs a) {
 #undef EF_FETCH
 #undef EF_TILE
 #undef EF_ST
+#undef EF_PIECE
+#undef EF_STAGE
   }
 }
 
@@ -502,7 +572,6 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
 // arithmetic plus one cross-half exchange per statistic.  Per row 256 B are read and 256 B written; the separate
 // kernels move 2.3 KB.
 // helpers of the bf16-pipeline forms below
-typedef unsigned ef_u32x2 __attribute__((ext_vector_type(2)));
 // one fp32 weight -> its three bf16 planes, `plane` elements apart
 __device__ __forceinline__ void ef_store_planes(unsigned short* dst, int plane, float w) {
   const unsigned u = __float_as_uint(w);
@@ -994,17 +1063,19 @@ static int edge_fused_fwd_impl(const float* E, const float* W12, const float* b1
   const bool wr = E12 != nullptr || train_form;    // training form: P (and E1|E2 when given) for every pair
   void (*k)(EdgeFusedArgs);
   bool lds_ok;
+  const bool coop = !mbvae_opt(MBVAE_OPT_NO_EF_COOP);
+#define EF_PICK(...) { k = __VA_ARGS__; lds_ok = MBVAE_ALLOW_BIG_LDS((__VA_ARGS__)); }
   if (bf16out) {
     if (!wr) return MBVAE_EINVAL;                    // bf16 storage is a training-form feature
-    k = edge_fused_fwd_kernel<true, true, true>;
-    lds_ok = MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true, true>));
+    if (coop) EF_PICK(edge_fused_fwd_kernel<true, true, true, true>) else EF_PICK(edge_fused_fwd_kernel<true, true, true>)
+  } else if (split && coop) {
+    if (wr) EF_PICK(edge_fused_fwd_kernel<true, true, false, true>) else EF_PICK(edge_fused_fwd_kernel<false, true, false, true>)
   } else if (split) {
-    k = wr ? edge_fused_fwd_kernel<true, true> : edge_fused_fwd_kernel<false, true>;
-    lds_ok = wr ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, true>));
+    if (wr) EF_PICK(edge_fused_fwd_kernel<true, true>) else EF_PICK(edge_fused_fwd_kernel<false, true>)
   } else {
-    k = wr ? edge_fused_fwd_kernel<true, false> : edge_fused_fwd_kernel<false, false>;
-    lds_ok = wr ? MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<true, false>)) : MBVAE_ALLOW_BIG_LDS((edge_fused_fwd_kernel<false, false>));
+    if (wr) EF_PICK(edge_fused_fwd_kernel<true, false>) else EF_PICK(edge_fused_fwd_kernel<false, false>)
   }
+#undef EF_PICK
   if (!lds_ok) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(bs * ichunks, cus);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, stream, a);

@@ -47,6 +47,8 @@ struct GemmArgs {
   const float* addend;
   // reduced-precision storage: the operand / output is bf16 in memory (only the bf16-pipeline edge kernels honour these)
   int a_bf16, b_bf16, c_bf16;
+  // wave-autonomous tall-skinny kernel only: columns per workgroup column group (blockIdx.y picks the group); 0 = all N
+  int col_group;
 };
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col, float keep_row) {
@@ -477,6 +479,17 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   constexpr int NP = ABF ? 4 : 8;                  // 16-byte words of A per lane and 64-wide reduction group
   constexpr unsigned CS = CBF ? 2u : 4u;           // bytes per output element
   constexpr int NT = 64 * WAVES;
+  // Column groups (weights too large for one workgroup's LDS, e.g. the 256 x 256 node-path layers): workgroup column
+  // blockIdx.y keeps only its `col_group` columns of the weights and produces only those output columns; everything
+  // below then sees an N = col_group problem whose B, C, bias and addend start at the group's first column.
+  const int col0 = g.col_group ? (int)blockIdx.y * g.col_group : 0;
+  if (g.col_group) {
+    g.N = g.col_group;
+    g.B += B_KC ? (int64_t)col0 * g.ldb : (int64_t)col0;
+    g.C = reinterpret_cast<float*>(reinterpret_cast<char*>(g.C) + (size_t)col0 * CS);
+    if (g.bias) g.bias += col0;
+    if (g.addend) g.addend += col0;
+  }
   const int N = g.N, LDB = N + 1;
   extern __shared__ __align__(16) float ts2_smem[];
   float* Bs = ts2_smem;                            // [K][LDB]
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
           }                                                                                            \
         }                                                                                              \
       } else {                                                                                         \
-        const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;              \
+        const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r + (unsigned)col0;   \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
@@ -755,16 +768,27 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   const bool bf16 = g.a_bf16 || g.c_bf16;
   if (g.b_bf16 || (bf16 && (g.a_gate || g.act || g.drop_p > 0.f || (g.bias && g.c_bf16) || g.a_gate_scale != 1.f)))
     return MBVAE_EUNSUPPORTED;
-  if (!aligned || g.M < 32768 || g.K % 32 || g.K > 512 || (int64_t)g.K * g.N > 32768) return MBVAE_EUNSUPPORTED;
+  // Node-path shapes (a few thousand rows, wide weights): the weights do not fit one workgroup's LDS, and there are too
+  // few rows to amortise staging all of them anyway.  Workgroup COLUMN groups of 64 output columns each stage only
+  // their slice (gridDim.y groups x row partitions).  Inside the train step this beats the generic LDS-tiled kernel
+  // for the 768-wide q|k|v projection (66 -> 53 us) and loses slightly at 256 wide (36 vs 40 us, although it wins
+  // in isolation: 24 vs 33 us), hence N >= 512.
+  int col_group = 0;
+  if (aligned && !bf16 && !mbvae_opt(MBVAE_OPT_NO_TSGEMM2) && !mbvae_opt(MBVAE_OPT_NO_COLGROUPS) && g.M >= 4096 && g.M % 32 == 0 &&
+      g.K % 64 == 0 && g.K <= 384 && g.N % 64 == 0 && g.N >= 512 && ((int64_t)g.K * g.N > 32768 || g.M < 32768) &&
+      !g.addend && !g.accumulate && (int64_t)g.M * g.ldc < 0x3fffffff)
+    col_group = 64;
+  if (!aligned || (!col_group && (g.M < 32768 || (int64_t)g.K * g.N > 32768)) || g.K % 32 || g.K > 512) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
   if ((bf16 || !mbvae_opt(MBVAE_OPT_NO_TSGEMM2)) && g.K % 64 == 0 && g.M % 32 == 0 && g.N % 64 == 0 && !g.accumulate &&
       !(g.addend && g.drop_p > 0.f) && (int64_t)g.M * g.ldc < 0x3fffffff) {
-    const int grid2 = std::min(std::max(g.M / 256, 1), ts_num_cus());
+    const int ngroups = col_group ? g.N / col_group : 1, neff = col_group ? col_group : g.N;
+    const int grid2 = std::min(std::max(g.M / 256, 1), std::max(ts_num_cus() / ngroups, 1));
     // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
-    const bool wide = g.N % 128 == 0 && !g.a_gate && !g.addend;
+    const bool wide = neff % 128 == 0 && !g.a_gate && !g.addend;
     const int waves = 8;
     // bf16-pipeline variants: weight planes pre-split in LDS where they fit, else split by the lanes as they are read
-    const size_t smem3 = 2 * 3 * (size_t)g.N * (g.K + 8), smemf = sizeof(float) * (size_t)g.K * (g.N + 1);
+    const size_t smem3 = 2 * 3 * (size_t)neff * (g.K + 8), smemf = sizeof(float) * (size_t)g.K * (neff + 1);
     const bool split = bf16 || !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
     const bool split1 = split && smem3 <= MBVAE_LDS_LIMIT, split2 = split && !split1;
     const size_t smem2 = split1 ? smem3 : smemf;
@@ -795,9 +819,12 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     TS2_PICK(true, tsgemm2_kernel<2, B_KC, false, 8>)
 #undef TS2_PICK
     if (!lds_ok || smem2 > MBVAE_LDS_LIMIT) return MBVAE_ELAUNCH;
-    hipLaunchKernelGGL(k, dim3(grid2), dim3(64 * waves), smem2, stream, g);
+    GemmArgs gl = g;
+    gl.col_group = col_group;
+    hipLaunchKernelGGL(k, dim3(grid2, ngroups), dim3(64 * waves), smem2, stream, gl);
     return mbvae_launch_status();
   }
+  if (col_group) return MBVAE_EUNSUPPORTED;
   if (bf16 || g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && mbvae_opt(MBVAE_OPT_TSGEMM_N64))) return MBVAE_EUNSUPPORTED;

@@ -53,6 +53,9 @@ def ragged_mask(bs, n, gen):
     (16 * 64 * 64, 128, 64, 0, "edge"), (9 * 64 * 64, 64, 256, 1, "edge"), (16 * 64 * 64, 128, 128, 1, "edge"),
     # fused e_mul|e_add projection and its gradients (weights up to 128 KB resident in LDS)
     (16 * 64 * 64, 64, 512, 0, "edge"),
+    # node-path shapes: column groups of the tall-skinny kernel (weights sliced over workgroup columns)
+    (4 * 64 * 64, 256, 768, 1, "edge"), (4 * 64 * 64, 256, 768, 0, "none"), (2 * 64 * 64, 128, 512, 1, "none"),
+    (4 * 64 * 64, 384, 640, 0, "edge"), (4 * 64 * 64, 256, 256, 1, "edge"),
     # few output tiles, long reduction: one 32x32 tile per workgroup, the reduction split over its four waves
     (256, 4170, 512, 0, "none"), (256, 1024, 2048, 1, "none"), (256, 256, 1024, 0, "none"), (32, 2048, 512, 1, "none"),
     (256, 2048, 100, 1, "none"), (200, 1000, 72, 0, "none"), (256, 512, 128, 1, "none"), (48, 136, 1024, 0, "none"),

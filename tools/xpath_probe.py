@@ -20,8 +20,8 @@ ws = ops.workspace(mask.device); st = torch.cuda.current_stream().cuda_stream
 for K, N in ((256, 256), (256, 768), (768, 256)):
     x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
     dy = torch.randn(M, N, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(b); y = torch.empty(M, N, device="cuda")
-    for tile in (-1, 0, 1, 2):
-        with _lib.option("GEMM_TILE", tile):
+    for tile in (-1, -2):                         # -2: column groups off (generic LDS-tiled kernel)
+        with _lib.option("NO_COLGROUPS", 1 if tile == -2 else 0):
             f = timeit(lambda: _lib.call("mbvae_linear_fwd", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, K, N, 0,
                                          m8.data_ptr(), ops.MASK_NODE, 64, 0.0, 0, 0, ws.data_ptr(), ws.numel(), st))
             d = timeit(lambda: _lib.call("mbvae_linear_bwd_input", dy.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, 0, 1.0,
