@@ -33,6 +33,25 @@ struct EdgeFusedArgs {
 
 __device__ __forceinline__ float4 ef_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// four consecutive fp32 values -> their three bf16 planes (8 bytes each), 4096 bytes apart, at dst
+__device__ __forceinline__ void ef_stage4(unsigned char* dst, float4 v4) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 ph, pm, pl;
+  const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2) {
+    const float a0 = xv[2 * p2], a1 = xv[2 * p2 + 1];
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    ph[p2] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    pm[p2] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(v0 & 0xffff0000u), q1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    pl[p2] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+  }
+  *reinterpret_cast<u32x2*>(dst) = ph; *reinterpret_cast<u32x2*>(dst + 4096) = pm; *reinterpret_cast<u32x2*>(dst + 8192) = pl;
+}
+
 // SPLIT: the projection runs on the bf16 matrix pipeline (six bf16 MFMAs per fp32 product, see mbvae_split8): the
 // lane's W12 slice is split once into three bf16 planes (96 registers instead of 64), the E rows are split in
 // registers right before their products, one split per 16 reduction indices shared by the E1 and the E2 tile.
@@ -401,7 +420,10 @@ struct EdgeFusedBwdArgs {
 };
 
 // BF16: dP is read and dE1|dE2 written as bf16 (the opt-in bf16 storage mode); everything else as in fp32.
-template <bool BF16>
+// COOP: the operand tile (the E rows of 32 keys) is fetched and split once per workgroup - each wave converts an eighth -
+// and shared as bf16 planes through 24 KB of LDS (two buffers, one barrier per query row), as in the forward; the
+// weight planes then get 16 LDS slots (hi, mid) and all eight lo planes sit in registers freed by the operand buffer.
+template <bool BF16, bool COOP>
 __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a) {
   constexpr int SS = BF16 ? 2 : 4;                  // bytes per dP / dE1|dE2 element
   // Register budget (256 per lane at 512 threads): the lane's W12 slice as three bf16 planes would take 96.  Most of
@@ -419,7 +441,8 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
 
   // 20 of the 24 (plane, octet, E1/E2) slots fill the CU's whole 160 KB of LDS (this kernel has no static __shared__
   // data): all hi and mid planes and four lo planes; the other four lo planes are registers.
-  constexpr int LO_LDS = 4;
+  constexpr int LO_LDS = COOP ? 0 : 4;
+  unsigned char* Ap = reinterpret_cast<unsigned char*>(ef_kv) + 16 * 512 * 16;   // COOP: [2 buffers][3 planes][32 keys][128 B]
   mbvae_bf16x8 lo[8];                                // lo planes, slot = 2 * octet + (E2 ? 1 : 0); slots < LO_LDS live in LDS
   {
     const float* p1 = a.W + (int64_t)c * 64 + 32 * h;
@@ -438,6 +461,10 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
   const float b1 = a.bias ? a.bias[c] : 0.f, b2 = a.bias ? a.bias[256 + c] : 0.f;
   const bool grpB = a.stagger == 1 ? wave >= 4 : (a.stagger == 2 ? (wave & 1) != 0 : false);
   float4 ra[8];
+  // COOP: this lane's share of a tile is 4 reduction indices of one key
+  const int prow_ = 4 * wave + (lane >> 4), pk4 = (lane & 15) * 4;
+  const int pst = prow_ * 128 + (((pk4 >> 3) ^ (prow_ & 7)) << 4) + ((pk4 >> 2) & 1) * 8;
+  float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int b = blockIdx.x; b < a.bs; b += gridDim.x) {
     const int64_t node = (int64_t)b * n;
@@ -456,7 +483,12 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
       const unsigned km32 = (unsigned)(kmask >> (32 * mt));
       const unsigned kml = km32 >> (4 * h);          // bit rr: this lane's key rr of the tile is valid
       const int jrow = min(32 * mt + r, n - 1);      // the key whose E row this lane feeds to the products
-      {
+      const int64_t pkey = min(32 * mt + prow_, n - 1);     // COOP: the key of this lane's share
+      if (COOP) {                                    // query row 0 into buffer 0, this lane's share of row 1 on its way
+        ef_stage4(Ap + pst, ef_ld4(a.E + ((node * n + pkey) * 64 + pk4)));
+        nx = ef_ld4(a.E + (((node + min(1, n - 1)) * n + pkey) * 64 + pk4));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+      } else {
         const float* src = a.E + ((node * n + jrow) * 64 + 32 * h);
 #pragma unroll
         for (int p = 0; p < 8; ++p) ra[p] = ef_ld4(src + 4 * p);
@@ -485,13 +517,28 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
         for (int v = 0; v < 16; ++v) { acc1[v] = b1; acc2[v] = b2; }
         // ONE operand buffer: an octet is dead once split, the next query row's octet is requested into the same registers
         const float* nsrc = a.E + (((node + min(i + 1, n - 1)) * n + jrow) * 64 + 32 * h);
+        if (COOP) {                                  // hand row i+1 to the other buffer, request this lane's share of row i+2
+          ef_stage4(Ap + ((i + 1) & 1) * 12288 + pst, nx);
+          nx = ef_ld4(a.E + (((node + min(i + 2, n - 1)) * n + pkey) * 64 + pk4));
+          asm volatile("" : : : "memory");
+        }
+        const unsigned char* Ab = Ap + (i & 1) * 12288 + r * 128;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          float4 t4 = ra[2 * o], u4 = ra[2 * o + 1];
-          asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory");
-          const MbvaeSplit3 as = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);
-          ra[2 * o] = ef_ld4(nsrc + 8 * o); ra[2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);
-          asm volatile("" : : : "memory");
+          MbvaeSplit3 as;
+          if (COOP) {
+            const int sw = ((4 * h + o) ^ (r & 7)) << 4;
+            as.hi = *reinterpret_cast<const mbvae_bf16x8*>(Ab + sw);
+            as.mid = *reinterpret_cast<const mbvae_bf16x8*>(Ab + 4096 + sw);
+            as.lo = *reinterpret_cast<const mbvae_bf16x8*>(Ab + 8192 + sw);
+            asm volatile("" : : : "memory");
+          } else {
+            float4 t4 = ra[2 * o], u4 = ra[2 * o + 1];
+            asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory");
+            as = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);
+            ra[2 * o] = ef_ld4(nsrc + 8 * o); ra[2 * o + 1] = ef_ld4(nsrc + 8 * o + 4);
+            asm volatile("" : : : "memory");
+          }
           if (qi_ok && km32 != 0u) {                  // a tile without a valid pair needs no products (wave-uniform)
             // weight planes are fetched from LDS one pair at a time, in the order lo, mid, hi, each right before its
             // products (8 registers in use at a time instead of 24); smaller terms still enter the sums first
@@ -513,7 +560,7 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
             }
           }
         }
-        const bool meet = (i & a.sync_mask) == a.sync_mask;
+        const bool meet = !COOP && (i & a.sync_mask) == a.sync_mask;
         if (meet && a.stagger != 0 && !grpB) asm volatile("s_barrier" : : : "memory");
         const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char*>(a.dE12) + qn * n * 512 * SS, 0, n * 512 * SS, 0x00020000);
@@ -547,6 +594,7 @@ __global__ __launch_bounds__(512) void edge_fused_bwd_kernel(EdgeFusedBwdArgs a)
         dq += __shfl_xor(dq, 32);
         if (h == 0) *dqp = dq_prev + dq;
         if (meet && (a.stagger == 0 || grpB)) asm volatile("s_barrier" : : : "memory");   // keep the waves together: they share the E rows in L1
+        if (COOP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");       // the other buffer is complete, this one is free
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -1131,15 +1179,19 @@ static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b1
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if (!mask || ((uintptr_t)b12 & 3)) return MBVAE_EINVAL;
   if (mbvae_opt(MBVAE_OPT_NO_EDGE_FUSED)) return MBVAE_EUNSUPPORTED;
-  constexpr int kLds = 20 * 512 * 16;                // 20 thread-private 16-byte slots = the CU's whole 160 KB
+  const bool coop = !mbvae_opt(MBVAE_OPT_NO_EFB_COOP);
+  constexpr int kLds = 20 * 512 * 16;                // 20 thread-private 16-byte slots = the CU's whole 160 KB (per-wave form)
+  constexpr int kLdsCoop = 16 * 512 * 16 + 2 * 12288;   // 16 weight slots + two operand tile buffers
   {
     static std::atomic<unsigned long long> done{0ull};   // per-device flag: the attribute is raised once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MBVAE_ELAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-      if (hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)edge_fused_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
         return MBVAE_ELAUNCH;
       done.fetch_or(bit, std::memory_order_release);
     }
@@ -1150,8 +1202,9 @@ static int edge_fused_bwd_impl(const float* E, const float* W12, const float* b1
   if (const int sy = mbvae_opt(MBVAE_OPT_EFB_SYNC); sy > 0) a.sync_mask = sy - 1;
   if (const int sg = mbvae_opt(MBVAE_OPT_EF_STAGGER); sg > 0) a.stagger = sg == 3 ? 0 : sg;
   const int grid = (int)std::min<int64_t>(bs, ef_num_cus());
-  auto k = bf16 ? edge_fused_bwd_kernel<true> : edge_fused_bwd_kernel<false>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), kLds, stream, a);
+  auto k = coop ? (bf16 ? edge_fused_bwd_kernel<true, true> : edge_fused_bwd_kernel<false, true>)
+                : (bf16 ? edge_fused_bwd_kernel<true, false> : edge_fused_bwd_kernel<false, false>);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), coop ? kLdsCoop : kLds, stream, a);
   return mbvae_launch_status();
 }
 
