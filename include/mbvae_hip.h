@@ -66,6 +66,16 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
                             const uint8_t* mask, int mask_mode, int n_nodes, int accumulate, void* workspace,
                             int64_t ws_bytes, mbvae_stream_t stream);
 
+/* Both gradients of one Linear layer from a single pass over dy (the backward of e_mul | e_add,
+ * graph_transformer.py:196-204, whose dy rows are the largest stream of a train step):
+ *   dx[M,K] = (addend +) rowmask(dy)[M,N] @ w[N,K];  dw[N,K] = rowmask(dy)^T @ x[M,K];  db[N] = column sums (may be NULL).
+ * Supported: K = 64, N = 512, M % 64 == 0, M >= 32768; otherwise -2 and the caller issues mbvae_linear_bwd_input(_add) and
+ * mbvae_linear_bwd_weight.  workspace: at least CUs * (N*K + N) * 4 bytes.  Bitwise reproducible. */
+int mbvae_linear_bwd_both(const float* dy, int64_t lddy, const float* w, const float* x, int64_t ldx, const float* addend,
+                          float* dx, int64_t lddx, float* dw, float* db, int64_t M, int64_t K, int64_t N,
+                          const uint8_t* mask, int mask_mode, int n_nodes, void* workspace, int64_t ws_bytes,
+                          mbvae_stream_t stream);
+
 /* ---- Edge-feature attention ------------------------------------------------------------------------
  * Replaces graph_transformer.py:206-249 (Y = Q*K/sqrt(df); Y*(E1+1)+E2; FiLM by y; per-channel masked
  * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx] with rows ldq floats apart and

@@ -1310,6 +1310,253 @@ __global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int spl
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Both gradients of the widest edge projection (64 -> 512: e_mul | e_add) from ONE pass over dY [M, 512]:
+//     dX = addend + keep(dY) W        dW = keep(dY)^T X        db = column sums of keep(dY)
+// As separate kernels each of them reads the 2 KB of a dY row from HBM; here the second reader finds it in the cache.
+// Wave w owns the 64 columns [64w, 64w+64) of dY for BOTH products, 16 rows at a time:
+//  * dW block [64 x 64] exactly as in the weight-gradient kernel above (lane (c, h) loads rows 8h .. 8h+7 of its two
+//    columns: the octets of the 32x32x16 operand; four accumulator tiles per wave for the whole kernel),
+//  * its share of dX [16 x 64] - the sum over its 64 columns - on the 16x16x32 shape, whose operand layout (lane
+//    (row, q) holds columns 8q .. 8q+7 of a 32-wide step) is the same tile read again row-wise, right after the first
+//    read brought it into L1/L2.  The weight slice is split once per kernel: hi and mid planes in thread-private LDS
+//    slots (128 KB), lo planes in registers.
+// The eight partial dX tiles meet in the remaining 32 KB of LDS (column blocks XOR-ed with the row quad: conflict-free
+// both ways) and are added in wave order, so dX is reproducible; dW / db partials go to the workspace for the same
+// fixed-order reduction kernel as above.
+struct ProjBwdArgs {
+  const float* dY; int lddy;
+  const float* X; int ldx;
+  const float* W;                       // [512][64]
+  const float* addend; float* dX; int lddx;
+  float* partial; float* partial_colsum;
+  const uint8_t* mask; int mask_mode; int n_nodes;
+  int nchunks;                          // M / 64
+};
+typedef float mbvae_f32x4 __attribute__((ext_vector_type(4)));
+#define PB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+template <bool HAS_ADD>
+__global__ __launch_bounds__(512) void proj_bwd_kernel(ProjBwdArgs g) {
+  extern __shared__ __align__(16) float pb_smem[];
+  // LDS (156 KB): 14 thread-private 16-byte slots with the hi planes (8) and six of the mid planes of the lane's W octets,
+  // the partial dX tiles [8 waves][16 rows][64], and two buffers with the bf16 planes of a group's X rows, which every
+  // wave multiplies with: split once per workgroup, laid out [plane][column parity][row half][column pair][8 rows] so
+  // that a lane's operand octet is one conflict-free 16-byte read
+  mbvae_bf16x8* wl = reinterpret_cast<mbvae_bf16x8*>(pb_smem);
+  float* part = pb_smem + 14 * 2048;
+  unsigned char* xp = reinterpret_cast<unsigned char*>(pb_smem) + 14 * 8192 + 32768;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;          // 32x32x16 operand coordinates (weight gradient)
+  const int m16 = lane & 15, q4 = lane >> 4;       // 16x16x32 operand coordinates (input gradient)
+  const int n0 = wave * 64;
+  const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+  const int my = (g.nchunks - bx + G - 1) / G;
+  const int total = my * 4;                         // 16-row groups of this workgroup
+
+  mbvae_bf16x8 wlo[8], wmr[2];                      // lo planes and the last two mid planes: registers
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      const float* wp = g.W + (int64_t)(n0 + 32 * t + 8 * q4) * 64 + 16 * et + m16;
+      const MbvaeSplit3 sp = mbvae_split8(wp[0], wp[64], wp[128], wp[192], wp[256], wp[320], wp[384], wp[448]);
+      wl[(4 * t + et) * 512 + tid] = sp.hi;
+      if (4 * t + et < 6) wl[(8 + 4 * t + et) * 512 + tid] = sp.mid; else wmr[4 * t + et - 6] = sp.mid;
+      wlo[4 * t + et] = sp.lo;
+    }
+
+  // all streams go through buffer descriptors rebuilt per 16-row group (scalar work): a lane keeps one 32-bit offset per
+  // stream instead of 64-bit addresses
+  typedef unsigned pb_u32x2 __attribute__((ext_vector_type(2)));
+  const int voA = (8 * h * g.lddy + n0 + 2 * c) * 4;
+  const int voD = (m16 * g.lddy + n0 + 8 * q4) * 4;
+  const int rrow = tid >> 5, re2 = (tid & 31) * 2;                 // this thread's dX outputs - and its share of the X rows: row rrow, columns re2, re2 + 1
+  const int rcol = re2 ^ (((rrow >> 2) & 3) << 4);
+  const int voR = (rrow * g.lddx + re2) * 4, voX = (rrow * g.ldx + re2) * 4;
+  const int szY = 16 * g.lddy * 4, szX = 16 * g.ldx * 4, szR = 16 * g.lddx * 4;
+  const int xw = (rrow >> 3) * 512 + (re2 >> 1) * 16 + (rrow & 7) * 2;   // where this thread's two X values go (column parity 0; +1024: parity 1)
+  const int xr = h * 512 + c * 16;                                       // this lane's operand octets
+  float2 ra[2][8], ad[2], xq;
+  unsigned ma[2], mb[2];
+  float cs0 = 0.f, cs1 = 0.f;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // The weight gradient's view of a dY tile (with the addend and the mask bytes) is prefetched one group ahead, the X
+  // rows two groups ahead; the input gradient's view is read when the group starts - the first read has brought the
+  // tile into L1/L2 by then - and BEFORE the next prefetch is issued: the memory counter is in order, so waiting for
+  // that read must not mean waiting for the prefetch.  (Letting the two waves of a SIMD take the products in opposite
+  // order, one splitting operands while the other multiplies, measured 14 % slower.)
+#define PB_ROW0(qq, c0, row)                                                                           \
+    const int gq_ = min((qq), total - 1);                                                              \
+    const int64_t c0 = (int64_t)(bx + (gq_ >> 2) * G) * 64;                                            \
+    const int64_t row = c0 + (gq_ & 3) * 16;
+#define PB_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (bytes), 0x00020000)
+#define PB_LOAD_COLS(dst, rsY)       /* weight-gradient view: rows 8h .. 8h+7 of the lane's two columns */ \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                      \
+      dst[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsY, voA, i * g.lddy * 4, 0));
+#define PB_LOAD_ROWS(dst, rsY)       /* input-gradient view: columns 8q .. 8q+7 of both 32-wide steps of the lane's row */ \
+    dst[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voD, 0, 0));        \
+    dst[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voD + 16, 0, 0));   \
+    dst[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voD + 128, 0, 0));  \
+    dst[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voD + 144, 0, 0));
+#define PB_LOAD_X(qq)                                                                                  \
+  {                                                                                                   \
+    PB_ROW0(qq, c0x, rowx)                                                                             \
+    xq = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(PB_RSRC(g.X + rowx * g.ldx, szX), voX, 0, 0)); \
+  }
+  // this thread's two X values -> their bf16 planes in buffer `buf`
+#define PB_STAGE_X(buf)                                                                               \
+  {                                                                                                   \
+    unsigned char* dst = xp + (buf) * 6144 + xw;                                                       \
+    const float xv[2] = {xq.x, xq.y};                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+      const unsigned u = __float_as_uint(xv[j]);                                                       \
+      const float r1 = xv[j] - __uint_as_float(u & 0xffff0000u);                                       \
+      const unsigned v = __float_as_uint(r1);                                                          \
+      const float r2 = r1 - __uint_as_float(v & 0xffff0000u);                                          \
+      *reinterpret_cast<unsigned short*>(dst + j * 1024) = (unsigned short)(u >> 16);                  \
+      *reinterpret_cast<unsigned short*>(dst + 2048 + j * 1024) = (unsigned short)(v >> 16);           \
+      *reinterpret_cast<unsigned short*>(dst + 4096 + j * 1024) = (unsigned short)(__float_as_uint(r2) >> 16); \
+    }                                                                                                  \
+  }
+#define PB_FETCH(qq, S)                                                                               \
+  {                                                                                                   \
+    PB_ROW0(qq, c0, row)                                                                               \
+    mbvae_row_mask_bytes(g.mask, g.mask_mode, c0 + lane, g.n_nodes, g.dY, ma[S], mb[S]);               \
+    const __amdgpu_buffer_rsrc_t rsY = PB_RSRC(g.dY + row * g.lddy, szY);                              \
+    PB_LOAD_COLS(ra[S], rsY)                                                                           \
+    if (HAS_ADD) ad[S] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(PB_RSRC(g.addend + row * g.lddx, szR), voR, 0, 0)); \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+#define PB_TERM(pa, pb)                                                                               \
+    acc[0][0] = MBVAE_MFMA_BF16(a0.pa, b0.pb, acc[0][0]); acc[0][1] = MBVAE_MFMA_BF16(a0.pa, b1.pb, acc[0][1]); \
+    acc[1][0] = MBVAE_MFMA_BF16(a1.pa, b0.pb, acc[1][0]); acc[1][1] = MBVAE_MFMA_BF16(a1.pa, b1.pb, acc[1][1]);
+  // masked rows of dY become zeros (selects: they may hold anything), column sums, then the four-tile product
+#define PB_WGRAD(RA, buf)                                                                             \
+    {                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+        float2 v = RA[i];                                                                              \
+        if (krows != 0xffffu) {                                                                        \
+          const bool kr = (kbits >> i) & 1u;                                                           \
+          v.x = kr ? v.x : 0.f; v.y = kr ? v.y : 0.f;                                                  \
+        }                                                                                              \
+        asm volatile("" : "+v"(v.x), "+v"(v.y) : : "memory");                                          \
+        cs0 += v.x; cs1 += v.y;                                                                        \
+        RA[i] = v;                                                                                     \
+      }                                                                                                \
+      const unsigned char* xb = xp + (buf) * 6144 + xr;                                                \
+      MbvaeSplit3 b0, b1;                                                                              \
+      b0.hi = *reinterpret_cast<const mbvae_bf16x8*>(xb);         b1.hi = *reinterpret_cast<const mbvae_bf16x8*>(xb + 1024);  \
+      b0.mid = *reinterpret_cast<const mbvae_bf16x8*>(xb + 2048); b1.mid = *reinterpret_cast<const mbvae_bf16x8*>(xb + 3072); \
+      b0.lo = *reinterpret_cast<const mbvae_bf16x8*>(xb + 4096);  b1.lo = *reinterpret_cast<const mbvae_bf16x8*>(xb + 5120);  \
+      const MbvaeSplit3 a0 = mbvae_split8(RA[0].x, RA[1].x, RA[2].x, RA[3].x, RA[4].x, RA[5].x, RA[6].x, RA[7].x); \
+      const MbvaeSplit3 a1 = mbvae_split8(RA[0].y, RA[1].y, RA[2].y, RA[3].y, RA[4].y, RA[5].y, RA[6].y, RA[7].y); \
+      PB_TERM(lo, hi) PB_TERM(hi, lo) PB_TERM(mid, mid) PB_TERM(mid, hi) PB_TERM(hi, mid) PB_TERM(hi, hi) \
+    }
+#define PB_DGRAD(DA)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                    \
+      float4 x0 = DA[2 * t], x1 = DA[2 * t + 1];                                                       \
+      asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w) : : "memory"); \
+      const MbvaeSplit3 a = mbvae_split8(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);              \
+      _Pragma("unroll") for (int et = 0; et < 4; ++et) {                                               \
+        const mbvae_bf16x8 wh = wl[(4 * t + et) * 512 + tid];                                          \
+        const mbvae_bf16x8 wm = 4 * t + et < 6 ? wl[(8 + 4 * t + et) * 512 + tid] : wmr[(4 * t + et - 6) & 1]; \
+        dxa[et] = PB_MFMA16(a.lo, wh, dxa[et]);  dxa[et] = PB_MFMA16(a.hi, wlo[4 * t + et], dxa[et]);  \
+        dxa[et] = PB_MFMA16(a.mid, wm, dxa[et]); dxa[et] = PB_MFMA16(a.mid, wh, dxa[et]);              \
+        dxa[et] = PB_MFMA16(a.hi, wm, dxa[et]);  dxa[et] = PB_MFMA16(a.hi, wh, dxa[et]);               \
+      }                                                                                                \
+    }
+#define PB_STEP(qq, S, S1)                                                                            \
+  {                                                                                                   \
+    PB_ROW0(qq, c0, row)                                                                               \
+    unsigned late;                                                                                     \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late) : : "memory");                                         \
+    const unsigned long long kb = __ballot(mbvae_mask_keep(g.mask_mode, ma[S] | late, mb[S] | late));  \
+    const unsigned krows = (unsigned)(kb >> ((gq_ & 3) * 16)) & 0xffffu;   /* bit i: row i of the group */ \
+    const unsigned kbits = krows >> (8 * h);                                                           \
+    mbvae_f32x4 dxa[4];                                                                                \
+    _Pragma("unroll") for (int et = 0; et < 4; ++et) dxa[et] = mbvae_f32x4{0.f, 0.f, 0.f, 0.f};        \
+    const __amdgpu_buffer_rsrc_t rsY2 = PB_RSRC(g.dY + row * g.lddy, szY);                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)        /* the prefetched view has landed */          \
+      asm volatile("" : "+v"(ra[S][i].x), "+v"(ra[S][i].y) : : "memory");                              \
+    float4 dl[4];                                                                                      \
+    PB_LOAD_ROWS(dl, rsY2)                                                                             \
+    asm volatile("" : : : "memory");                                                                   \
+    PB_FETCH((qq) + 1, S1)                                                                             \
+    PB_LOAD_X((qq) + 2)                                                                                \
+    asm volatile("" : : : "memory");                                                                   \
+    PB_WGRAD(ra[S], S)                                                                                 \
+    PB_DGRAD(dl)                                                                                       \
+    asm volatile("s_barrier" : : : "memory");          /* the previous group's partial tiles have been read; every wave is done with this group's X planes */ \
+    _Pragma("unroll") for (int et = 0; et < 4; ++et)                                                   \
+      _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                    \
+        part[wave * 1024 + (4 * q4 + v) * 64 + ((et ^ q4) << 4) + m16] = dxa[et][v];                   \
+    PB_STAGE_X(S)                                      /* the group after next: read two barriers from here */ \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");                                  \
+    {                                                                                                  \
+      float2 s2 = *reinterpret_cast<const float2*>(part + rrow * 64 + rcol);                           \
+      _Pragma("unroll") for (int w = 1; w < 8; ++w) {                                                  \
+        const float2 p2 = *reinterpret_cast<const float2*>(part + w * 1024 + rrow * 64 + rcol);        \
+        s2.x += p2.x; s2.y += p2.y;                                                                    \
+      }                                                                                                \
+      const bool kr = (krows >> rrow) & 1u;                                                            \
+      s2.x = kr ? s2.x : 0.f; s2.y = kr ? s2.y : 0.f;                                                  \
+      if (HAS_ADD) { s2.x += ad[S].x; s2.y += ad[S].y; }                                               \
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pb_u32x2, s2), PB_RSRC(g.dX + row * g.lddx, szR), voR, 0, 0); \
+    }                                                                                                  \
+  }
+
+  PB_LOAD_X(0)
+  PB_STAGE_X(0)
+  PB_LOAD_X(1)
+  PB_STAGE_X(1)
+  PB_FETCH(0, 0)
+  __syncthreads();
+  for (int q = 0; q < total; q += 2) {
+    PB_STEP(q, 0, 1)
+    PB_STEP(q + 1, 1, 0)
+  }
+#undef PB_ROW0
+#undef PB_RSRC
+#undef PB_LOAD_COLS
+#undef PB_LOAD_ROWS
+#undef PB_LOAD_X
+#undef PB_STAGE_X
+#undef PB_FETCH
+#undef PB_TERM
+#undef PB_WGRAD
+#undef PB_DGRAD
+#undef PB_STEP
+
+  // partial dW of this workgroup: tile (i, j) holds rows 64 wave + 2 m + i, columns 2 c + j
+  float* pw = g.partial + (int64_t)bx * 512 * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = (v & 3) + 8 * (v >> 2) + 4 * h;
+      const int row = wave * 64 + 2 * m + i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pw[row * 64 + 2 * c + j] = acc[i][j][v];
+    }
+  if (g.partial_colsum != nullptr) {
+    cs0 += __shfl_xor(cs0, 32, 64);
+    cs1 += __shfl_xor(cs1, 32, 64);
+    if (h == 0) {
+      g.partial_colsum[(int64_t)bx * 512 + wave * 64 + 2 * c] = cs0;
+      g.partial_colsum[(int64_t)bx * 512 + wave * 64 + 2 * c + 1] = cs1;
+    }
+  }
+}
+
 // returns MBVAE_EUNSUPPORTED when the shape does not qualify (the caller then uses the generic kernel)
 static int tswgrad_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (mbvae_opt(MBVAE_OPT_NO_TSWGRAD)) return MBVAE_EUNSUPPORTED;
@@ -1762,6 +2009,51 @@ int mbvae_linear_bwd_weight_bf16(const void* dy, int dy_bf16, int64_t lddy, cons
   g.a_gate_scale = 1.f; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes; g.colsum = db;
   g.a_bf16 = dy_bf16 != 0; g.b_bf16 = x_bf16 != 0;
   return gemm_dispatch<false, false>(g, workspace, ws_bytes, stream);
+}
+
+// Both gradients of a Linear layer from one pass over dy:  dx = (addend +) rowmask(dy) @ w,  dw = rowmask(dy)^T @ x,
+// db = column sums (may be NULL).  Only the widest edge projection qualifies (K = 64 inputs, N = 512 outputs,
+// M >= 32768 rows, M % 64 == 0); everything else returns "unsupported" and the caller issues the two separate calls.
+// workspace: at least CUs * (N * K + N) * 4 bytes.
+int mbvae_linear_bwd_both(const float* dy, int64_t lddy, const float* w, const float* x, int64_t ldx, const float* addend,
+                          float* dx, int64_t lddx, float* dw, float* db, int64_t M, int64_t K, int64_t N,
+                          const uint8_t* mask, int mask_mode, int n_nodes, void* workspace, int64_t ws_bytes,
+                          hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !w || !x || !dx || !dw || M <= 0) return MBVAE_EINVAL;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (mbvae_opt(MBVAE_OPT_NO_BWD_BOTH) || mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA)) return MBVAE_EUNSUPPORTED;
+  const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)addend | (uintptr_t)w) & 15) == 0 &&
+                       (lddy & 3) == 0 && (ldx & 1) == 0 && (lddx & 1) == 0;
+  if (K != 64 || N != 512 || M % 64 || M < 32768 || !aligned || (M + 16) * lddy >= 0x7fffffff || workspace == nullptr)
+    return MBVAE_EUNSUPPORTED;
+  const int nchunks = (int)(M / 64);
+  const int grid = std::min(nchunks, mbvae_num_cus());
+  if (ws_bytes < (int64_t)grid * (512 * 64 + 512) * 4) return MBVAE_EUNSUPPORTED;
+  constexpr int kLds = 14 * 8192 + 32768 + 2 * 6144;
+  {
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MBVAE_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute((const void*)proj_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)proj_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+        return MBVAE_ELAUNCH;
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  ProjBwdArgs a;
+  a.dY = dy; a.lddy = (int)lddy; a.X = x; a.ldx = (int)ldx; a.W = w; a.addend = addend; a.dX = dx; a.lddx = (int)lddx;
+  a.partial = (float*)workspace;
+  a.partial_colsum = db ? a.partial + (int64_t)grid * 512 * 64 : nullptr;
+  a.mask = mask; a.mask_mode = mask_mode; a.n_nodes = n_nodes; a.nchunks = nchunks;
+  if (addend) hipLaunchKernelGGL(proj_bwd_kernel<true>, dim3(grid), dim3(512), kLds, stream, a);
+  else hipLaunchKernelGGL(proj_bwd_kernel<false>, dim3(grid), dim3(512), kLds, stream, a);
+  GemmArgs r{};
+  r.M = 512; r.N = 64; r.C = dw; r.ldc = 64; r.partial = a.partial; r.partial_colsum = a.partial_colsum; r.colsum = db; r.accumulate = 0;
+  hipLaunchKernelGGL(tswgrad_reduce_kernel, dim3((unsigned)((512 * 64 + 512 + 63) / 64)), dim3(256), 0, stream, r, grid);
+  return mbvae_launch_status();
 }
 
 }  // extern "C"

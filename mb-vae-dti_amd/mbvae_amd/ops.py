@@ -220,6 +220,21 @@ def _edge_input_grads(E, w, m8, stats, arg, n_nodes, has_bias, dy, dstats, dres,
     dE = dw = db = None
     bf16 = dy is not None and dy.dtype == torch.bfloat16        # bf16 storage mode: the projection output's gradient
     dy2 = (dy.contiguous() if bf16 else _f32c(dy, "dy")).reshape(M, N) if dy is not None else None
+    if need_dE and need_dw and dy2 is not None and not bf16 and K == 64 and N == 512:
+        # both gradients from one pass over dy (the widest projection: its 2 KB rows are the largest stream of the step)
+        dres = _f32c(dres, "dres") if dres is not None else None
+        dE = torch.empty_like(E)
+        dw = torch.empty((N, K), dtype=torch.float32, device=E.device)
+        db = torch.empty((N,), dtype=torch.float32, device=E.device) if has_bias else None
+        both = _lib.call("mbvae_linear_bwd_both", dy2.data_ptr(), N, w.data_ptr(), x2.data_ptr(), K, _ptr(dres), dE.data_ptr(), K,
+                         dw.data_ptr(), _ptr(db), M, K, N, m8.data_ptr(), MASK_EDGE, n_nodes, ws.data_ptr(), ws.numel(), st,
+                         tag=(M, K, N), allow_unsupported=True)
+        if both:
+            if dstats is not None:
+                _lib.call("mbvae_pool_stats_bwd", E.data_ptr(), stats.data_ptr(), arg.data_ptr(), _f32c(dstats).data_ptr(),
+                          dE.data_ptr(), bs, L, D, 1, st)
+            return dE, dw, db
+        dE = dw = db = None
     if need_dE:
         dE = torch.empty_like(E)
         have = False

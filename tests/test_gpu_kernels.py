@@ -29,7 +29,7 @@ def default_routes():
     """Tests that assert WHICH entry points ran pin the library's route switches to their defaults (the suite may be
     run with MBVAE_NO_SPLIT_MFMA / MBVAE_NO_E12_RECOMPUTE in the environment to exercise the other routes)."""
     from mbvae_amd import _lib
-    with _lib.option("NO_SPLIT_MFMA", 0), _lib.option("NO_E12_RECOMPUTE", 0):
+    with _lib.option("NO_SPLIT_MFMA", 0), _lib.option("NO_E12_RECOMPUTE", 0), _lib.option("NO_BWD_BOTH", 0):
         yield
 
 
@@ -791,6 +791,52 @@ def test_edge_input_fanout(ops, bs, n, de, N):
     assert_close(yg, y, what="projection"); assert_close(sg, stats, what="pool stats"); assert torch.equal(alias, Eg)
     assert_close(Eg.grad, Er.grad, what="dE"); assert_close(wg.grad, wr.grad, what="dw")
     assert_close(bg.grad, br.grad, what="db")
+
+
+@pytest.mark.parametrize("bs,n,with_add,ragged", [(16, 64, True, True), (9, 64, False, True), (32, 32, True, False)])
+def test_projection_backward_single_pass(ops, bs, n, with_add, ragged, default_routes):
+    """mbvae_linear_bwd_both (input gradient, weight gradient and bias gradient of the 64 -> 512 projection from one
+    pass over dy) against an fp64 restatement and against the two separate entry points; bitwise equal run to run."""
+    K, N = 64, 512
+    M = bs * n * n
+    g = torch.Generator().manual_seed(bs * 7 + n)
+    mask = (ragged_mask(bs, n, g) if ragged else torch.ones(bs, n, dtype=torch.bool)).cuda()
+    dy = torch.randn(M, N, generator=g).cuda(); x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / 8).cuda()
+    add = torch.randn(M, K, generator=g).cuda() if with_add else None
+    m8 = mask.view(torch.uint8)
+    ws = ops.workspace(dy.device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def both():
+        dx = torch.empty(M, K, device="cuda"); dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+        _lib.call("mbvae_linear_bwd_both", dy.data_ptr(), N, w.data_ptr(), x.data_ptr(), K, add.data_ptr() if with_add else None,
+                  dx.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, K, N, m8.data_ptr(), ops.MASK_EDGE, n, ws.data_ptr(), ws.numel(), st)
+        return dx, dw, db
+
+    dx, dw, db = both()
+    keep = (mask.unsqueeze(1) & mask.unsqueeze(2)).reshape(M, 1).double()
+    dyk = dy.double() * keep
+    dx_ref = dyk @ w.double() + (add.double() if with_add else 0.0)
+    assert_close(dx, dx_ref.float(), what="dx"); assert_close(dw, (dyk.t() @ x.double()).float(), what="dw")
+    assert_close(db, dyk.sum(0).float(), what="db")
+    dx2, dw2, db2 = both()
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2), "not reproducible"
+    # the separate kernels
+    dxs = torch.empty(M, K, device="cuda"); dws = torch.empty(N, K, device="cuda"); dbs = torch.empty(N, device="cuda")
+    if with_add:
+        _lib.call("mbvae_linear_bwd_input_add", dy.data_ptr(), N, w.data_ptr(), add.data_ptr(), dxs.data_ptr(), K, M, K, N, 0, 1.0,
+                  m8.data_ptr(), ops.MASK_EDGE, n, st)
+    else:
+        _lib.call("mbvae_linear_bwd_input", dy.data_ptr(), N, w.data_ptr(), dxs.data_ptr(), K, M, K, N, 0, 1.0,
+                  m8.data_ptr(), ops.MASK_EDGE, n, 0, ws.data_ptr(), ws.numel(), st)
+    _lib.call("mbvae_linear_bwd_weight", dy.data_ptr(), N, x.data_ptr(), K, dws.data_ptr(), dbs.data_ptr(), M, K, N, 0, 1.0,
+              m8.data_ptr(), ops.MASK_EDGE, n, 0, ws.data_ptr(), ws.numel(), st)
+    assert_close(dx, dxs, what="dx vs separate"); assert_close(dw, dws, what="dw vs separate"); assert_close(db, dbs, what="db vs separate")
+    with _lib.option("NO_BWD_BOTH", 1):
+        assert not _lib.call("mbvae_linear_bwd_both", dy.data_ptr(), N, w.data_ptr(), x.data_ptr(), K, None, dx.data_ptr(), K,
+                             dw.data_ptr(), db.data_ptr(), M, K, N, m8.data_ptr(), ops.MASK_EDGE, n, ws.data_ptr(), ws.numel(), st,
+                             allow_unsupported=True)
 
 
 def _edge_block_reference(E, w12, b12, QKV, ya, ym, mask, n_head):
