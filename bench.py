@@ -81,9 +81,14 @@ def kernel_table(profile):
         r["ms"] += ms
         r["calls"] += len(evs)
         if tag is not None and name.startswith("mbvae_linear"):
-            M, K, N = tag
-            r["flops"] += 2.0 * M * K * N * len(evs)
+            r["flops"] += linear_flops(name, tag) * len(evs)
     return rows
+
+
+def linear_flops(name, tag):
+    """fp32-equivalent flops of one launch: 2*M*K*N per product (the single-pass backward holds two)."""
+    M, K, N = tag
+    return (4.0 if name == "mbvae_linear_bwd_both" else 2.0) * M * K * N
 
 
 def launch_workers(n):
@@ -199,7 +204,7 @@ def main():
             for (name, tag), (ms, calls) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:24]:
                 M, K, N = tag
                 print(f"  {name[6:]:18s} M={M:<8d} K={K:<5d} N={N:<5d} {ms / args.steps:8.3f} ms/step {calls // args.steps:4d} calls  "
-                      f"{2.0 * M * K * N * calls / (ms * 1e-3) / 1e12:6.1f} TFLOP/s", file=sys.stderr)
+                      f"{linear_flops(name, tag) * calls / (ms * 1e-3) / 1e12:6.1f} TFLOP/s", file=sys.stderr)
             print(f"{'sum of HIP kernels':32s} {tot / args.steps:9.3f} ms/step;  wall {1000 * elapsed / args.steps:.3f} ms/step",
                   file=sys.stderr)
         # Dominant kernel = the (entry point, shape) with the largest share of the timed region.  Projections are
@@ -214,14 +219,16 @@ def main():
                     "mbvae_edge_fused_fwd": s * (bs * n * n * (de + 3 * dx) + 4 * bs * n * dx),
                     # the default training pair: forward E in, P out; backward E, dP in, dE1|dE2 out (E1|E2 recomputed)
                     "mbvae_edge_fused_fwd_recompute": s * (bs * n * n * (de + dx) + 4 * bs * n * dx),
-                    "mbvae_edge_fused_bwd": s * (bs * n * n * (de + 3 * dx) + 10 * bs * n * dx)}
+                    "mbvae_edge_fused_bwd": s * (bs * n * n * (de + 3 * dx) + 10 * bs * n * dx),
+                    # both gradients of the e_mul|e_add projection from one pass: dE1|dE2, E, addend in; dE out (+ weights)
+                    "mbvae_linear_bwd_both": s * (bs * n * n * (2 * dx + 3 * de) + 2 * (2 * dx * de))}
         cands = []
         for (name, tag), evs in profile.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)
-            if name.startswith("mbvae_linear") and tag is not None:
-                cands.append((ms, name, tag, len(evs)))
-            elif name in ea_bytes:
+            if name in ea_bytes:                 # streaming kernels: priced against HBM
                 cands.append((ms, name, None, len(evs)))
+            elif name.startswith("mbvae_linear") and tag is not None:
+                cands.append((ms, name, tag, len(evs)))
         ms, name, tag, calls = max(cands)
         avg_ms = ms / calls
         traffic_tbl = {}
@@ -244,7 +251,7 @@ def main():
         roofline["traffic"] = traffic_tbl.get(key, {}).get("bytes")
         roofline["avg_launch_ms"] = round(avg_ms, 4)
         roofline["launches_per_step"] = calls // args.steps
-        lin = [rows.get(k, {"ms": 0.0, "flops": 0.0}) for k in ("mbvae_linear_fwd", "mbvae_linear_bwd_input", "mbvae_linear_bwd_weight")]
+        lin = [r for k, r in rows.items() if k.startswith("mbvae_linear")]
         lin_ms, lin_flops = sum(r["ms"] for r in lin), sum(r["flops"] for r in lin)
         roofline["all_projections_TFLOPs"] = round(lin_flops / max(lin_ms, 1e-9) / 1e9, 2)
         # matrix-core busy fraction of the edge projections from the committed counter pass
@@ -273,7 +280,7 @@ def main():
         for (nm, tg), evs in profile.items():
             if nm.startswith("mbvae_linear") and tg is not None and tg[0] == bs * n * n and min(tg[1], tg[2]) >= 64:
                 e_ms += sum(a.elapsed_time(b) for a, b in evs)
-                e_fl += 2.0 * tg[0] * tg[1] * tg[2] * len(evs)
+                e_fl += linear_flops(nm, tg) * len(evs)
         if e_ms > 0:
             roofline["edge_projections_TFLOPs"] = round(e_fl / e_ms / 1e9, 2)
             roofline["edge_projections_frac_of_fp32_mfma_peak"] = round(e_fl / e_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)

@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict
   }
 }
 
-// out[c] = sum_p part[p][c], c < width  (second stage of the per-block partial sums).
+// (c < half ? out0[c] : out1[c - half]) = sum_p part[p][c], c < width  (second stage of the per-block partial sums; the
+// two halves are dgamma and dbeta, written straight to their destinations).
 // block = 32 columns x 8 partial groups; fixed summation order -> deterministic.
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int nparts, int width) {
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int nparts, int width, int half) {
   __shared__ float red[8][33];
   const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][cx];
-    out[c] = t;
+    if (c < half) out0[c] = t; else out1[c - half] = t;
   }
 }
 
@@ -198,11 +199,8 @@ static int ln_launch(bool fwd, const float* x, const float* r, const float* gamm
     if (blocks < 1) return MBVAE_EINVAL;
     hipLaunchKernelGGL((ln_res_bwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean,
                        rstd, dy, dx, dr, part, rows, drop_p, seed);
-    // part is [blocks][2][D]: view as [blocks][2D] and sum -> [2D] = dgamma | dbeta (contiguous in `part` tail)
-    float* tail = part + blocks * 2 * D;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, part, tail, (int)blocks, 2 * D);
-    if (hipMemcpyAsync(dgamma, tail, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
-    if (hipMemcpyAsync(dbeta, tail + D, sizeof(float) * D, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MBVAE_ELAUNCH;
+    // part is [blocks][2][D]: view as [blocks][2D] and sum -> dgamma | dbeta
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, part, dgamma, dbeta, (int)blocks, 2 * D, D);
   }
   return mbvae_launch_status();
 }

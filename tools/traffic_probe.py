@@ -42,6 +42,20 @@ def lin(K, N, act=0, drop=0.0):
 with torch.enable_grad():
     lin(64, 512); lin(256, 64); lin(64, 128, act=1, drop=0.1); lin(128, 64)
     mark("setup")                      # input generation between the ops lands in "setup" segments (ignored)
+    # both gradients of the 64 -> 512 projection from one pass over dy (entry point called directly)
+    from mbvae_amd import _lib as _lb
+    dyb = torch.randn(M, 512, device=dev); xb = torch.randn(M, 64, device=dev); wb = torch.randn(512, 64, device=dev) / 8
+    addb = torch.randn(M, 64, device=dev); dxb = torch.empty(M, 64, device=dev)
+    dwb = torch.empty(512, 64, device=dev); dbb = torch.empty(512, device=dev)
+    wsb = ops.workspace(dyb.device)
+    args_both = (dyb.data_ptr(), 512, wb.data_ptr(), xb.data_ptr(), 64, addb.data_ptr(), dxb.data_ptr(), 64, dwb.data_ptr(), dbb.data_ptr(),
+                 M, 64, 512, mask.view(torch.uint8).data_ptr(), 2, n, wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
+    _lb.call("mbvae_linear_bwd_both", *args_both)
+    torch.cuda.synchronize()
+    mark("mbvae_linear_bwd_both")
+    _lb.call("mbvae_linear_bwd_both", *args_both)
+    mark("setup")
+    del dyb, xb, addb, dxb
     QKV = torch.randn(bs, n, 3 * dx, device=dev, requires_grad=True)
     E12 = (torch.randn(bs, n, n, 2 * dx, device=dev) * 0.5).requires_grad_(True)
     ya = torch.randn(bs, dx, device=dev, requires_grad=True); ym = torch.randn(bs, dx, device=dev, requires_grad=True)
