@@ -60,6 +60,12 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
 int mbvae_linear_bwd_input_add(const float* dy, int64_t lddy, const float* w, const float* addend, float* dx,
                                int64_t lddx, int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
                                const uint8_t* mask, int mask_mode, int n_nodes, mbvae_stream_t stream);
+/* dx[M,K] = out_gate[M,K] > 0 ? (rowmask(dy)[M,N] @ w[N,K]) * out_gate_scale : 0.  out_gate is this layer's INPUT when that
+ * input came out of ReLU (+ dropout) - linE2 / linX2 / lin_y2 of the feed-forward blocks, graph_transformer.py:139-146 -:
+ * the gate of the layer below is applied where the gradient is produced, and that layer's gradient calls take gate = NULL. */
+int mbvae_linear_bwd_input_outgate(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t M, int64_t K,
+                                   int64_t N, const float* out_gate, float out_gate_scale, const uint8_t* mask, int mask_mode,
+                                   int n_nodes, void* workspace, int64_t ws_bytes, mbvae_stream_t stream);
 /* dw[N,K] (+)= pro(dy)[M,N]^T @ x[M,K];  db[N] = column sums of pro(dy) (db may be NULL) */
 int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                             int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,

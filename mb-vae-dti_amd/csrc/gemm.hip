@@ -45,6 +45,9 @@ struct GemmArgs {
   int k_per_split; float* partial; float* partial_colsum;
   // optional addend with C's layout (C = epi(...) + addend): only the wave-autonomous tall-skinny kernel applies it
   const float* addend;
+  // optional output gate with C's layout (C = c_gate > 0 ? epi(...) * c_gate_scale : 0): the ReLU / dropout gate of the
+  // layer BELOW applied where this layer's input gradient is produced; only the wave-autonomous tall-skinny kernel
+  const float* c_gate; float c_gate_scale;
   // reduced-precision storage: the operand / output is bf16 in memory (only the bf16-pipeline edge kernels honour these)
   int a_bf16, b_bf16, c_bf16;
   // wave-autonomous tall-skinny kernel only: columns per workgroup column group (blockIdx.y picks the group); 0 = all N
@@ -473,9 +476,10 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 // its B octets as well, right after reading them - more vector work per MFMA, still ahead of the fp32 MFMA.
 // ABF / CBF: A is read / C is written as bf16 (the opt-in bf16 storage of the large edge activations).  A bf16 operand
 // IS its own hi plane, so its products need three MFMAs instead of six.
-template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false>
+template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false, bool CGATE = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   static_assert(!(ABF && (GATE || SPLIT == 0)), "a bf16 A operand runs on the bf16 pipeline and has no gate");
+  static_assert(!(ADD && CGATE) && !(CGATE && CBF), "an output gate comes without an addend and with fp32 output");
   constexpr int NP = ABF ? 4 : 8;                  // 16-byte words of A per lane and 64-wide reduction group
   constexpr unsigned CS = CBF ? 2u : 4u;           // bytes per output element
   constexpr int NT = 64 * WAVES;
@@ -689,19 +693,21 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
       const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * CS;   /* wave-uniform byte offset */ \
       float bn[TN];                                                                                    \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = bjr[1 - S][j] * has_bias;                 \
-      if (ADD) {                                       /* all addend loads first, then one wait */     \
+      if (ADD || CGATE) {                              /* all addend / gate loads first, then one wait */ \
         const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;              \
+        const float* adp = CGATE ? g.c_gate : g.addend;                                                \
         float ad[TN][16];                                                                              \
         _Pragma("unroll") for (int v = 0; v < 16; ++v)                                                 \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
-            ad[j][v] = g.addend[off0 + (unsigned)((v & 3) + 8 * (v >> 2)) * ldc + j * 32];             \
+            ad[j][v] = adp[off0 + (unsigned)((v & 3) + 8 * (v >> 2)) * ldc + j * 32];                  \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
           const int rr = (v & 3) + 8 * (v >> 2);                                                       \
           const bool kr = (kh >> rr) & 1u;                                                             \
           _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                             \
             float o = acc[j][v];                                                                       \
             if (relu) o = fmaxf(o, 0.f);                                                               \
-            TS2_ST((kr ? o : 0.f) + ad[j][v], rr, j, sbase);                                           \
+            if (CGATE) TS2_ST((kr && ad[j][v] > 0.f) ? o * g.c_gate_scale : 0.f, rr, j, sbase);        \
+            else TS2_ST((kr ? o : 0.f) + ad[j][v], rr, j, sbase);                                      \
           }                                                                                            \
         }                                                                                              \
       } else if (!drop && !relu && kb == ~0ull) {      /* nothing but the stores */                    \
@@ -768,6 +774,9 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   const bool bf16 = g.a_bf16 || g.c_bf16;
   if (g.b_bf16 || (bf16 && (g.a_gate || g.act || g.drop_p > 0.f || (g.bias && g.c_bf16) || g.a_gate_scale != 1.f)))
     return MBVAE_EUNSUPPORTED;
+  if (g.c_gate && (bf16 || g.a_gate || g.addend || g.act || g.drop_p > 0.f || g.accumulate || ((uintptr_t)g.c_gate & 15) ||
+                   (int64_t)g.K * g.N > 25600))
+    return MBVAE_EUNSUPPORTED;
   // Node-path shapes (a few thousand rows, wide weights): the weights do not fit one workgroup's LDS, and there are too
   // few rows to amortise staging all of them anyway.  Workgroup COLUMN groups of 64 output columns each stage only
   // their slice (gridDim.y groups x row partitions).  Inside the train step this beats the generic LDS-tiled kernel
@@ -776,7 +785,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
   int col_group = 0;
   if (aligned && !bf16 && !mbvae_opt(MBVAE_OPT_NO_TSGEMM2) && !mbvae_opt(MBVAE_OPT_NO_COLGROUPS) && g.M >= 4096 && g.M % 32 == 0 &&
       g.K % 64 == 0 && g.K <= 384 && g.N % 64 == 0 && g.N >= 512 && ((int64_t)g.K * g.N > 32768 || g.M < 32768) &&
-      !g.addend && !g.accumulate && (int64_t)g.M * g.ldc < 0x3fffffff)
+      !g.addend && !g.c_gate && !g.accumulate && (int64_t)g.M * g.ldc < 0x3fffffff)
     col_group = 64;
   if (!aligned || (!col_group && (g.M < 32768 || (int64_t)g.K * g.N > 32768)) || g.K % 32 || g.K > 512) return MBVAE_EUNSUPPORTED;
   // the wave-autonomous kernel keeps only the weights in LDS (up to 128 KB of them)
@@ -785,7 +794,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     const int ngroups = col_group ? g.N / col_group : 1, neff = col_group ? col_group : g.N;
     const int grid2 = std::min(std::max(g.M / 256, 1), std::max(ts_num_cus() / ngroups, 1));
     // 4 column tiles per wave (64 stores per lane and task) unless the gate operand needs the registers
-    const bool wide = neff % 128 == 0 && !g.a_gate && !g.addend;
+    const bool wide = neff % 128 == 0 && !g.a_gate && !g.addend && !g.c_gate;
     const int waves = 8;
     // bf16-pipeline variants: weight planes pre-split in LDS where they fit, else split by the lanes as they are read
     const size_t smem3 = 2 * 3 * (size_t)neff * (g.K + 8), smemf = sizeof(float) * (size_t)g.K * (neff + 1);
@@ -804,6 +813,9 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
       TS2_PICK(!ab && cb && split1 && wide, tsgemm2_kernel<4, B_KC, false, 8, false, 1, false, true>)
       if (k == nullptr) return MBVAE_EUNSUPPORTED;
     }
+    TS2_PICK(split1 && g.c_gate, tsgemm2_kernel<2, B_KC, false, 8, false, 1, false, false, true>)
+    TS2_PICK(g.c_gate && !split, tsgemm2_kernel<2, B_KC, false, 8, false, 0, false, false, true>)
+    if (g.c_gate && k == nullptr) return MBVAE_EUNSUPPORTED;
     TS2_PICK(split1 && wide, tsgemm2_kernel<4, B_KC, false, 8, false, 1>)
     TS2_PICK(split1 && g.addend && g.a_gate, tsgemm2_kernel<2, B_KC, true, 8, true, 1>)
     TS2_PICK(split1 && g.addend, tsgemm2_kernel<2, B_KC, false, 8, true, 1>)
@@ -825,7 +837,7 @@ static int tsgemm_try(const GemmArgs& g, hipStream_t stream) {
     return mbvae_launch_status();
   }
   if (col_group) return MBVAE_EUNSUPPORTED;
-  if (bf16 || g.addend || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
+  if (bf16 || g.addend || g.c_gate || g.K > 256 || (int64_t)g.K * g.N > 16384) return MBVAE_EUNSUPPORTED;
   // 64-wide outputs are HBM-bound on the A stream; the generic kernel keeps more loads in flight per CU there (measured).
   if (g.N != 128 && g.N != 256 && !(g.N == 64 && mbvae_opt(MBVAE_OPT_TSGEMM_N64))) return MBVAE_EUNSUPPORTED;
   const int BM = g.N == 256 ? 128 : 256;
@@ -1873,6 +1885,12 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   return mbvae_launch_status();
 }
 
+// x = gate > 0 ? x * scale : 0, element-wise (the fallback of mbvae_linear_bwd_input_outgate)
+__global__ __launch_bounds__(256) void out_gate_kernel(float* __restrict__ x, const float* __restrict__ gate, float scale, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    x[e] = gate[e] > 0.f ? x[e] * scale : 0.f;
+}
+
 extern "C" {
 
 // Process-wide tuning switch `name` (without the MBVAE_ prefix, e.g. "NO_EDGE_FUSED"); see MbvaeOption.
@@ -1958,6 +1976,36 @@ int mbvae_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64
   g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
   g.accumulate = accumulate; g.colsum = db;
   return gemm_dispatch<false, false>(g, workspace, ws_bytes, stream);
+}
+
+// dx[M,K] = out_gate[M,K] > 0 ? (rowmask(dy)[M,N] @ w[N,K]) * out_gate_scale : 0   (out_gate laid out like dx)
+// The input gradient of a layer whose INPUT came out of ReLU (+ dropout): out_gate is that input, so the gate of the
+// layer below is applied here, where the gradient is produced, and that layer's own gradient kernels read an already
+// gated dy (mbvae_linear_bwd_input* / _bwd_weight with gate = NULL).  Edge-path shapes apply the gate in the product's
+// epilogue; any other shape runs the plain product followed by one element-wise pass.
+int mbvae_linear_bwd_input_outgate(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t M, int64_t K,
+                                   int64_t N, const float* out_gate, float out_gate_scale, const uint8_t* mask, int mask_mode,
+                                   int n_nodes, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M > 0x7fffffff || K > 0x7fffffff || N > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (!out_gate || lddx != K) return MBVAE_EINVAL;
+  GemmArgs g = {};
+  g.A = dy; g.B = w; g.C = dx; g.M = (int)M; g.N = (int)K; g.K = (int)N;
+  g.lda = lddy; g.ldb = K; g.ldc = lddx;
+  g.a_gate_scale = 1.f; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.c_gate = out_gate; g.c_gate_scale = out_gate_scale;
+  if (dy && w && dx && M > 0 && K > 0 && N > 0) {
+    const int st = tsgemm_try<false>(g, stream);
+    if (st != MBVAE_EUNSUPPORTED) return st;
+  }
+  g.c_gate = nullptr;
+  const int st = gemm_dispatch<true, false>(g, workspace, ws_bytes, stream);
+  if (st != MBVAE_OK) return st;
+  const int64_t total = M * K;
+  hipLaunchKernelGGL(out_gate_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, stream, dx, out_gate,
+                     out_gate_scale, total);
+  return mbvae_launch_status();
 }
 
 // ---- bf16 storage of the edge block's large activations (opt-in; fp32 weights, fp32 accumulation) ----------------

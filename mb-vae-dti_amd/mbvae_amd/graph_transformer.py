@@ -163,8 +163,8 @@ class XEyTransformerLayer(nn.Module):
         def ff_block(ln, l1, l2, x):
             """norm(x + dropout(l2(dropout(relu(l1(x)))))); the residual branch uses l1's alias of x so that both
             gradients of x meet inside l1's input-gradient product."""
-            h, x = _lin(l1, x, act=1, drop_p=p, seed=seeds.next(), with_alias=True)
-            return norm(ln, x, _lin(l2, h))
+            out, x = ops.ffn(x, l1.weight, l1.bias, l2.weight, l2.bias, drop_p=p, seed=seeds.next())
+            return norm(ln, x, out)
 
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
         if inference:                                     # the edge feed-forward block in one pass

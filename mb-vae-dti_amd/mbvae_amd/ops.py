@@ -81,7 +81,10 @@ class _Linear(torch.autograd.Function):
     folded into the input-gradient product's epilogue instead of meeting it in a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias):
+    def forward(ctx, x, w, b, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias, in_gate_scale, pregated):
+        """in_gate_scale (float or None): x came out of ReLU (+ dropout with that keep scale) of the layer below and has
+        no other consumer: this layer's backward applies that gate to the input gradient it produces.  pregated: the
+        counterpart on the layer below (act == 1): its dy arrives already gated."""
         bf16_in = x.dtype == torch.bfloat16          # bf16 storage mode: the attention output P feeding e_out
         if bf16_in:
             if not x.is_cuda or act or drop_p > 0 or with_alias:
@@ -102,9 +105,11 @@ class _Linear(torch.autograd.Function):
             _lib.call("mbvae_linear_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), y.data_ptr(), N, M, K, N, act,
                       _ptr(m8), mask_mode, n_nodes, float(drop_p), int(seed), 0, ws.data_ptr(), ws.numel(), _stream(),
                       tag=(M, K, N))
-        gated = act == 1
+        gated = act == 1 and not pregated
         ctx.save_for_backward(x2, w, y if gated else None, m8)
         ctx.cfg = (mask_mode, n_nodes, float(drop_p), gated, b is not None, x.shape)
+        ctx.in_gate_scale = in_gate_scale
+        ctx.relu = act == 1
         out = y.reshape(*x.shape[:-1], N)
         return (out, x.view_as(x)) if with_alias else out
 
@@ -117,8 +122,8 @@ class _Linear(torch.autograd.Function):
         dy2 = _f32c(dy, "dy").reshape(M, N)
         ws = workspace(dy.device)
         gscale = 1.0 / (1.0 - drop_p) if (gated and drop_p > 0) else 1.0
-        # a ReLU gate (y > 0) already implies the row mask
-        mm = MASK_NONE if gated else mask_mode
+        # a ReLU gate (y > 0) already implies the row mask (also when the layer above has applied it to dy)
+        mm = MASK_NONE if ctx.relu else mask_mode
         dx = dw = db = None
         if x2.dtype == torch.bfloat16:               # bf16 storage mode: dx leaves as bf16, x is read as bf16
             if ctx.needs_input_grad[0]:
@@ -134,8 +139,15 @@ class _Linear(torch.autograd.Function):
                           M, K, N, _ptr(m8), mm, n_nodes, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
                 if not ctx.needs_input_grad[1]:
                     dw = None
-            return dx, dw, db, None, None, None, None, None, None, None
-        if ctx.needs_input_grad[0]:
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
+        if ctx.needs_input_grad[0] and ctx.in_gate_scale is not None:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _lib.call("mbvae_linear_bwd_input_outgate", dy2.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, M, K, N, x2.data_ptr(),
+                      float(ctx.in_gate_scale), _ptr(m8), mm, n_nodes, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
+            if dres is not None:
+                dx += _f32c(dres, "dres").reshape(M, K)
+            dx = dx.reshape(xshape)
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             folded = False
             if dres is not None:
@@ -157,17 +169,38 @@ class _Linear(torch.autograd.Function):
                       _ptr(gate), gscale, _ptr(m8), mm, n_nodes, 0, ws.data_ptr(), ws.numel(), _stream(), tag=(M, K, N))
             if not ctx.needs_input_grad[1]:
                 dw = None
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=0, drop_p=0.0, seed=0, with_alias=False):
+def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=0, drop_p=0.0, seed=0, with_alias=False,
+           in_gate_scale=None, pregated=False):
     """y = rowmask(dropout(act(x @ W^T + b))); act: 0 none, 1 ReLU.  Dropout is only supported after ReLU.
-    with_alias=True returns (y, alias of x): use the alias for x's other consumer (residual branch)."""
+    with_alias=True returns (y, alias of x): use the alias for x's other consumer (residual branch).
+    in_gate_scale / pregated: see ffn() - a ReLU layer's gate applied by the backward of its only consumer."""
     if drop_p > 0 and act != 1:
         raise ValueError("dropout in the GEMM epilogue is only implemented after ReLU")
     if mask is None:
         mask_mode = MASK_NONE
-    return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias)
+    if pregated and act != 1:
+        raise ValueError("pregated is the counterpart of a ReLU layer")
+    return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias, in_gate_scale, pregated)
+
+
+def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None):
+    """(l2(dropout(relu(l1(x)))), alias of x for the residual branch): the two Linears of a feed-forward block
+    (graph_transformer.py:139-146).  The hidden activation h has exactly one consumer, so with `handover` the ReLU /
+    dropout gate of l1 is applied by l2's backward where it produces dh (h itself is the gate) and l1's two gradient
+    kernels read the gated dh without loading h again: 0.5 KB less traffic per row.  Default: on for the edge path
+    (>= 32768 rows), where the gate sits in the product's epilogue; the short node / global paths keep the gate inside
+    l1's kernels (one launch fewer)."""
+    if handover is None:
+        handover = x.numel() // x.shape[-1] >= 32768 and not _lib.load().mbvae_get_option(b"NO_FFN_HANDOVER")
+    if not handover:
+        h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True)
+        return linear(h, w2, b2), xa
+    scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+    h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True, pregated=True)
+    return linear(h, w2, b2, in_gate_scale=scale), xa
 
 
 # ------------------------------------------------------------------------------------------------ edge-tensor fan-out

@@ -793,6 +793,49 @@ def test_edge_input_fanout(ops, bs, n, de, N):
     assert_close(bg.grad, br.grad, what="db")
 
 
+@pytest.mark.parametrize("M,d,dff", [(16 * 64 * 64, 64, 128), (4 * 64 * 64, 256, 512), (256, 1024, 1024), (300, 24, 40)])
+def test_ffn_gate_handover(ops, M, d, dff, default_routes):
+    """ops.ffn: the ReLU gate of the first Linear is applied by the second one's input-gradient call (in the product's
+    epilogue at the edge widths, by an element-wise pass elsewhere); values and all gradients against plain torch, and
+    against the two-Linear composition that gates inside the first layer's gradient kernels."""
+    g = torch.Generator().manual_seed(M + d)
+    # x, w1, b1 are small multiples of 1/8: every pre-activation is then exact in fp32 on any summation order, so the
+    # GPU and the CPU reference take the same side of every ReLU gate (a flipped gate is an O(1) gradient difference)
+    x = torch.randint(-8, 9, (M, d), generator=g).float() / 8
+    w1 = torch.randint(-8, 9, (dff, d), generator=g).float() / 8; b1 = torch.randint(-8, 9, (dff,), generator=g).float() / 8
+    w2 = torch.randn(d, dff, generator=g) / math.sqrt(dff); b2 = torch.randn(d, generator=g) * 0.1
+    cy, cx = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    hr = F.relu(F.linear(ref[0], ref[1], ref[2]))
+    ((F.linear(hr, ref[3], ref[4]) * cy).sum() + (ref[0] * cx).sum()).backward()
+
+    def run(handover):
+        ins = [t.clone().cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        _lib.PROFILE = {}
+        try:
+            if handover:
+                y, xa = ops.ffn(*ins, handover=True)
+            else:
+                h, xa = ops.linear(ins[0], ins[1], ins[2], act=1, with_alias=True)
+                y = ops.linear(h, ins[3], ins[4])
+            ((y * cy.cuda()).sum() + (xa * cx.cuda()).sum()).backward()
+            torch.cuda.synchronize()
+            called = {name for name, _ in _lib.PROFILE}
+        finally:
+            _lib.PROFILE = None
+        return y.detach(), [t.grad for t in ins], called
+
+    y, grads, called = run(True)
+    assert "mbvae_linear_bwd_input_outgate" in called
+    assert_close(y, F.linear(F.relu(F.linear(x, w1, b1)), w2, b2), what="ffn output")
+    for got, t, name in zip(grads, ref, ("dx", "dw1", "db1", "dw2", "db2")):
+        assert_close(got, t.grad, what=name)
+    y0, grads0, called0 = run(False)
+    assert "mbvae_linear_bwd_input_outgate" not in called0 and torch.equal(y, y0)
+    for a, b_, name in zip(grads, grads0, ("dx", "dw1", "db1", "dw2", "db2")):
+        assert_close(a, b_, what=name + " hand-over vs in-layer gate")
+
+
 @pytest.mark.parametrize("bs,n,with_add,ragged", [(16, 64, True, True), (9, 64, False, True), (32, 32, True, False)])
 def test_projection_backward_single_pass(ops, bs, n, with_add, ragged, default_routes):
     """mbvae_linear_bwd_both (input gradient, weight gradient and bias gradient of the 64 -> 512 projection from one
