@@ -42,6 +42,18 @@ def lin(K, N, act=0, drop=0.0):
 with torch.enable_grad():
     lin(64, 512); lin(256, 64); lin(64, 128, act=1, drop=0.1); lin(128, 64)
     mark("setup")                      # input generation between the ops lands in "setup" segments (ignored)
+    # linE2's input gradient with the ReLU / dropout gate of linE1 applied in its epilogue (entry point called directly)
+    from mbvae_amd import _lib as _lg
+    dyg = torch.randn(M, 64, device=dev); wg = torch.randn(64, 128, device=dev) / 11; hg = torch.randn(M, 128, device=dev)
+    dhg = torch.empty(M, 128, device=dev); wsg = ops.workspace(dyg.device)
+    args_g = (dyg.data_ptr(), 64, wg.data_ptr(), dhg.data_ptr(), 128, M, 128, 64, hg.data_ptr(), 1.0 / 0.9, None, 0, 0,
+              wsg.data_ptr(), wsg.numel(), torch.cuda.current_stream().cuda_stream)
+    _lg.call("mbvae_linear_bwd_input_outgate", *args_g)
+    torch.cuda.synchronize()
+    mark("mbvae_linear_bwd_input_outgate:1048576x128x64")
+    _lg.call("mbvae_linear_bwd_input_outgate", *args_g)
+    mark("setup")
+    del dyg, hg, dhg
     # both gradients of the 64 -> 512 projection from one pass over dy (entry point called directly)
     from mbvae_amd import _lib as _lb
     dyb = torch.randn(M, 512, device=dev); xb = torch.randn(M, 64, device=dev); wb = torch.randn(512, 64, device=dev) / 8
