@@ -169,8 +169,17 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  if (c < width)
-    for (int p = py; p < nparts; p += 8) s += part[(int64_t)p * width + c];
+  if (c < width) {
+    // four independent chains: the loads of a chain are issued back to back instead of one per memory round trip
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = py;
+    for (; p + 24 < nparts; p += 32) {
+      s0 += part[(int64_t)p * width + c];        s1 += part[(int64_t)(p + 8) * width + c];
+      s2 += part[(int64_t)(p + 16) * width + c]; s3 += part[(int64_t)(p + 24) * width + c];
+    }
+    for (; p < nparts; p += 8) s0 += part[(int64_t)p * width + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[py][cx] = s;
   __syncthreads();
   if (py == 0 && c < width) {
