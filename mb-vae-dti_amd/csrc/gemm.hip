@@ -302,7 +302,13 @@ __global__ void gemm_reduce_kernel(GemmArgs g, int splits) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + g.M; e += (int64_t)gridDim.x * blockDim.x) {
     if (e < total) {
       float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += g.partial[(int64_t)z * total + e];
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {               // four loads in flight; the additions keep their order
+        const float a0 = g.partial[(int64_t)z * total + e], a1 = g.partial[(int64_t)(z + 1) * total + e];
+        const float a2 = g.partial[(int64_t)(z + 2) * total + e], a3 = g.partial[(int64_t)(z + 3) * total + e];
+        s += a0; s += a1; s += a2; s += a3;
+      }
+      for (; z < splits; ++z) s += g.partial[(int64_t)z * total + e];
       const int row = (int)(e / g.N), col = (int)(e - (int64_t)row * g.N);
       const float keep = mbvae_row_keep(g.mask, g.c_mask_mode, row, g.n_nodes);
       g.C[(int64_t)row * g.ldc + col] = gemm_epilogue(g, s, row, col, keep);
