@@ -1337,8 +1337,9 @@ __global__ __launch_bounds__(256) void tswgrad_reduce_kernel(GemmArgs g, int spl
 //    columns: the octets of the 32x32x16 operand; four accumulator tiles per wave for the whole kernel),
 //  * its share of dX [16 x 64] - the sum over its 64 columns - on the 16x16x32 shape, whose operand layout (lane
 //    (row, q) holds columns 8q .. 8q+7 of a 32-wide step) is the same tile read again row-wise, right after the first
-//    read brought it into L1/L2.  The weight slice is split once per kernel: hi and mid planes in thread-private LDS
-//    slots (128 KB), lo planes in registers.
+//    read brought it into L1/L2.  The weight slice is split once per kernel: the hi and six of the mid planes in
+//    thread-private LDS slots (112 KB), the other planes in registers.  The X rows of a group, which all eight waves
+//    multiply with, are split once per workgroup into bf16 planes in LDS, two groups ahead.
 // The eight partial dX tiles meet in the remaining 32 KB of LDS (column blocks XOR-ed with the row quad: conflict-free
 // both ways) and are added in wave order, so dX is reproducible; dW / db partials go to the workspace for the same
 // fixed-order reduction kernel as above.
