@@ -82,6 +82,15 @@ int mbvae_linear_bwd_both(const float* dy, int64_t lddy, const float* w, const f
                           const uint8_t* mask, int mask_mode, int n_nodes, void* workspace, int64_t ws_bytes,
                           mbvae_stream_t stream);
 
+/* Node update modulated by the global features (graph_transformer.py:254: newX = yx1 + (yx2 + 1) * weighted_V):
+ * out[b,i,:] = add[b,:] + (mul[b,:] + 1) * x[b,i,:];  x, out [bs,n,D], add, mul [bs,D], D % 4 == 0, 16-byte aligned.
+ * Backward: dx = dout * (mul + 1), dadd[b,:] = sum_i dout[b,i,:], dmul[b,:] = sum_i dout[b,i,:] * x[b,i,:] (node order,
+ * bitwise reproducible). */
+int mbvae_film_fwd(const float* add, const float* mul, const float* x, float* out, int64_t bs, int64_t n, int64_t D,
+                   mbvae_stream_t stream);
+int mbvae_film_bwd(const float* dout, const float* mul, const float* x, float* dx, float* dadd, float* dmul, int64_t bs,
+                   int64_t n, int64_t D, mbvae_stream_t stream);
+
 /* ---- Edge-feature attention ------------------------------------------------------------------------
  * Replaces graph_transformer.py:206-249 (Y = Q*K/sqrt(df); Y*(E1+1)+E2; FiLM by y; per-channel masked
  * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx] with rows ldq floats apart and

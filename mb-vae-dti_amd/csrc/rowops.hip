@@ -524,6 +524,39 @@ __global__ __launch_bounds__(256) void ln_res_bwd_generic_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node update modulated by the global features:  out[b,i,c] = add[b,c] + (mul[b,c] + 1) * x[b,i,c]   (x, out [bs,n,D]).
+// Forward: element-wise, 16 bytes per lane.  Backward: one workgroup per graph, a lane owns channels and walks the n
+// nodes: dx = dout * (mul + 1), dadd = sum_i dout, dmul = sum_i dout * x in node order (no atomics: reproducible).
+__global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ add, const float* __restrict__ mul,
+                                                       const float* __restrict__ x, float* __restrict__ out, int64_t total4,
+                                                       int nD4, int D4) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / nD4;
+    const int c4 = (int)(e % D4);
+    const float4 a = ld4(add + (b * D4 + c4) * 4), m = ld4(mul + (b * D4 + c4) * 4), v = ld4(x + e * 4);
+    st4(out + e * 4, make_float4(a.x + (m.x + 1.f) * v.x, a.y + (m.y + 1.f) * v.y, a.z + (m.z + 1.f) * v.z, a.w + (m.w + 1.f) * v.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ mul,
+                                                       const float* __restrict__ x, float* __restrict__ dx,
+                                                       float* __restrict__ dadd, float* __restrict__ dmul, int n, int D) {
+  const int64_t b = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float m1 = mul[b * D + c] + 1.f;
+    float sa = 0.f, sm = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const int64_t off = (b * n + i) * D + c;
+      const float g = dout[off];
+      dx[off] = g * m1;
+      sa += g; sm += g * x[off];
+    }
+    dadd[b * D + c] = sa; dmul[b * D + c] = sm;
+  }
+}
+
 extern "C" {
 
 // y = LayerNorm(x + dropout_p(r)) * gamma + beta over the last dim D; r may be null.  Saves mean/rstd [rows].
@@ -707,6 +740,28 @@ int mbvae_sym_mask(const float* x, const float* s, int64_t lds, const uint8_t* m
                               (int)n, (int)D, zero_diag);
   else hipLaunchKernelGGL(sym_mask_kernel<1>, dim3((unsigned)(bs * n)), dim3(256), 0, stream, x, s, (int)lds, mask, out,
                           (int)n, (int)D, zero_diag);
+  return mbvae_launch_status();
+}
+
+// out[b,i,:] = add[b,:] + (mul[b,:] + 1) * x[b,i,:]   (x, out [bs,n,D]; add, mul [bs,D]; D % 4 == 0)
+int mbvae_film_fwd(const float* add, const float* mul, const float* x, float* out, int64_t bs, int64_t n, int64_t D,
+                   hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!add || !mul || !x || !out || bs <= 0 || n <= 0 || D <= 0) return MBVAE_EINVAL;
+  if (D % 4 || (((uintptr_t)add | (uintptr_t)mul | (uintptr_t)x | (uintptr_t)out) & 15) || n * D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  const int64_t total4 = bs * n * D / 4;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 8192)), dim3(256), 0, stream, add, mul, x,
+                     out, total4, (int)(n * D / 4), (int)(D / 4));
+  return mbvae_launch_status();
+}
+
+// dx = dout * (mul + 1);  dadd[b,:] = sum_i dout[b,i,:];  dmul[b,:] = sum_i dout[b,i,:] * x[b,i,:]
+int mbvae_film_bwd(const float* dout, const float* mul, const float* x, float* dx, float* dadd, float* dmul, int64_t bs,
+                   int64_t n, int64_t D, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !mul || !x || !dx || !dadd || !dmul || bs <= 0 || n <= 0 || D <= 0) return MBVAE_EINVAL;
+  if (bs > 0x7fffffff || n > 0x7fffffff || D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
+  hipLaunchKernelGGL(film_bwd_kernel, dim3((unsigned)bs), dim3(256), 0, stream, dout, mul, x, dx, dadd, dmul, (int)n, (int)D);
   return mbvae_launch_status();
 }
 

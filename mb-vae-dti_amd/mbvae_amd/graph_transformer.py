@@ -113,7 +113,8 @@ class NodeEdgeBlock(nn.Module):
         if pack is not None:
             film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
         elif torch.is_grad_enabled():
-            film = yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV
+            film = (ops.film(yx_add, yx_mul, wV) if dx % 4 == 0 and not ops.option_set("NO_FILM")
+                    else yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV)
         else:                                  # same arithmetic in two element-wise kernels instead of three
             film = torch.addcmul(yx_add.unsqueeze(1), yx_mul.unsqueeze(1) + 1, wV)
         newX = _lin(self.x_out, film, **node)

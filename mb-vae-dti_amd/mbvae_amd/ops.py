@@ -61,6 +61,11 @@ def _work_counter(device):
     return q
 
 
+def option_set(name):
+    """Current value of a process-wide library switch (mbvae_get_option) as a bool."""
+    return _lib.load().mbvae_get_option(name.encode()) > 0
+
+
 def _f32c(t, name="tensor"):
     if not t.is_cuda or t.dtype != torch.float32:
         raise RuntimeError(f"{name}: expected a float32 tensor on the GPU (got {t.dtype} on {t.device}); "
@@ -194,7 +199,7 @@ def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None):
     (>= 32768 rows), where the gate sits in the product's epilogue; the short node / global paths keep the gate inside
     l1's kernels (one launch fewer)."""
     if handover is None:
-        handover = x.numel() // x.shape[-1] >= 32768 and not _lib.load().mbvae_get_option(b"NO_FFN_HANDOVER")
+        handover = x.numel() // x.shape[-1] >= 32768 and not option_set("NO_FFN_HANDOVER")
     if not handover:
         h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True)
         return linear(h, w2, b2), xa
@@ -751,6 +756,35 @@ class _SymMask(torch.autograd.Function):
 def sym_mask(x, node_mask, skip=None, zero_diag=False):
     """0.5*(x + x^T (+ skip + skip^T)) * pair mask (* off-diagonal).  `skip` contributes its first D features."""
     return _SymMask.apply(x, skip, node_mask, zero_diag)
+
+
+# ------------------------------------------------------------------------------------------------ FiLM of the node update
+class _Film(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, add, mul, x):
+        add, mul, x = _f32c(add, "add"), _f32c(mul, "mul"), _f32c(x, "x")
+        bs, n, D = x.shape
+        out = torch.empty_like(x)
+        _lib.call("mbvae_film_fwd", add.data_ptr(), mul.data_ptr(), x.data_ptr(), out.data_ptr(), bs, n, D, _stream())
+        ctx.save_for_backward(mul, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mul, x = ctx.saved_tensors
+        bs, n, D = x.shape
+        dout = _f32c(dout, "dout")
+        dx = torch.empty_like(x)
+        dadd, dmul = torch.empty_like(mul), torch.empty_like(mul)
+        _lib.call("mbvae_film_bwd", dout.data_ptr(), mul.data_ptr(), x.data_ptr(), dx.data_ptr(), dadd.data_ptr(), dmul.data_ptr(),
+                  bs, n, D, _stream())
+        return dadd, dmul, dx
+
+
+def film(add, mul, x):
+    """add[:, None] + (mul[:, None] + 1) * x for x [bs,n,D], add / mul [bs,D] (graph_transformer.py:254) in one kernel
+    each way (the torch expression is three launches forward and five backward)."""
+    return _Film.apply(add, mul, x)
 
 
 # ------------------------------------------------------------------------------------------------ losses

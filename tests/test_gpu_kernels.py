@@ -793,6 +793,30 @@ def test_edge_input_fanout(ops, bs, n, de, N):
     assert_close(bg.grad, br.grad, what="db")
 
 
+@pytest.mark.parametrize("bs,n,D", [(256, 64, 256), (3, 9, 16), (5, 33, 520)])
+def test_film(ops, bs, n, D):
+    """add + (mul + 1) * x over the nodes of a graph (graph_transformer.py:254): values and the three gradients against
+    the torch expression; bitwise equal from run to run."""
+    g = torch.Generator().manual_seed(bs + n + D)
+    add, mul, x, c = (torch.randn(*sh, generator=g) for sh in ((bs, D), (bs, D), (bs, n, D), (bs, n, D)))
+    ref = [t.clone().requires_grad_(True) for t in (add, mul, x)]
+    yr = ref[0].unsqueeze(1) + (ref[1].unsqueeze(1) + 1) * ref[2]
+    (yr * c).sum().backward()
+
+    def run():
+        ins = [t.clone().cuda().requires_grad_(True) for t in (add, mul, x)]
+        y = ops.film(*ins)
+        (y * c.cuda()).sum().backward()
+        return y.detach(), [t.grad for t in ins]
+
+    y, grads = run()
+    assert_close(y, yr, what="film")
+    for got, t, name in zip(grads, ref, ("dadd", "dmul", "dx")):
+        assert_close(got, t.grad, what=name)
+    y2, grads2 = run()
+    assert torch.equal(y, y2) and all(torch.equal(a, b_) for a, b_ in zip(grads, grads2))
+
+
 @pytest.mark.parametrize("M,d,dff", [(16 * 64 * 64, 64, 128), (4 * 64 * 64, 256, 512), (256, 1024, 1024), (300, 24, 40)])
 def test_ffn_gate_handover(ops, M, d, dff, default_routes):
     """ops.ffn: the ReLU gate of the first Linear is applied by the second one's input-gradient call (in the product's
