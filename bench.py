@@ -247,6 +247,11 @@ def main():
             key = name
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+            lin_tags = [t for (nm, t) in profile if nm == name and t is not None]
+            if name.startswith("mbvae_linear") and lin_tags:      # a streaming GEMM: also its fp32-equivalent rate
+                fl = linear_flops(name, lin_tags[0]) / (avg_ms * 1e-3) / 1e12
+                roofline["fp32_equiv_TFLOPs"] = round(fl, 2)
+                roofline["frac_of_fp32_mfma_peak"] = round(fl / MFMA_F32_PEAK_TFLOPS, 4)
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE)
         roofline["traffic"] = traffic_tbl.get(key, {}).get("bytes")
         roofline["avg_launch_ms"] = round(avg_ms, 4)
