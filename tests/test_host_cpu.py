@@ -64,10 +64,13 @@ def test_schedule_mirror_matches_golden():
     from mbvae_amd.diffusion import MarginalUniformTransition, PredefinedNoiseScheduleDiscrete
     g = load_golden("schedule")
     ns = PredefinedNoiseScheduleDiscrete(500)
-    assert torch.equal(ns.betas, g["betas"]) and torch.equal(ns.alphas_bar, g["alphas_bar"])
+    # exp(cumsum(log .)) in fp32 rounds differently from one CPU's vector ISA to the next: 5e-6 element-wise, not bit-equal
+    def ulp_close(a, b):
+        return bool(((a.double() - b.double()).abs() <= 5e-6 * b.double().abs()).all())
+    assert torch.equal(ns.betas, g["betas"]) and ulp_close(ns.alphas_bar, g["alphas_bar"])
     t = g["t_int"] / 500
     assert torch.equal(ns(t_normalized=t), g["beta_t"])
-    assert torch.equal(ns.get_alpha_bar(t_normalized=(g["t_int"] - 1) / 500), g["alpha_s_bar"])   # t=0 -> index -1 wraps
+    assert ulp_close(ns.get_alpha_bar(t_normalized=(g["t_int"] - 1) / 500), g["alpha_s_bar"])   # t=0 -> index -1 wraps
     tm = MarginalUniformTransition(g["mx"], g["me"], 4)
     assert torch.equal(tm.get_Qt(g["beta_t"], "cpu").X, g["Qt_X"]) and torch.equal(tm.get_Qt_bar(g["alpha_t_bar"], "cpu").E, g["Qtb_E"])
     assert "betas" in ns.state_dict()

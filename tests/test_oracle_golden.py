@@ -5,16 +5,24 @@ from tests._util import assert_close, load_golden
 from oracle import denoiser as O_den, diffusion as O_dif, features as O_feat, heads as O_heads
 
 
+def _ulp_close(a, b):
+    """alphas_bar = exp(cumsum(log(1 - beta))) in fp32: torch's vectorised exp / log round differently from one CPU's
+    vector ISA to the next (a few ulp at the end of a 501-term sum of magnitude 20), so the host that wrote the fixture
+    and the host that runs this test agree element-wise to 5e-6, not bit for bit."""
+    assert a.shape == b.shape and bool(((a.double() - b.double()).abs() <= 5e-6 * b.double().abs()).all())
+
+
 def test_schedule_known_answers():
     g = load_golden("schedule")
     sch = O_dif.Schedule(500)
-    assert torch.equal(sch.betas, g["betas"]) and torch.equal(sch.alphas_bar, g["alphas_bar"])
+    assert torch.equal(sch.betas, g["betas"])
+    _ulp_close(sch.alphas_bar, g["alphas_bar"])
     assert abs(float(sch.betas[0]) - 8.723023e-05) < 1e-10 and float(sch.betas[500]) == 1.0
     assert abs(float(sch.alphas_bar[250]) - 0.492289) < 1e-6
     assert torch.equal(O_dif.Qt(g["beta_t"], g["mx"]), g["Qt_X"])
     assert torch.equal(O_dif.Qt_bar(g["alpha_t_bar"], g["me"]), g["Qtb_E"])
     # t = 0 -> s = -1 wraps to alphas_bar[T]
-    assert torch.equal(sch.alpha_bar(t_normalized=(g["t_int"] - 1) / 500), g["alpha_s_bar"])
+    _ulp_close(sch.alpha_bar(t_normalized=(g["t_int"] - 1) / 500), g["alpha_s_bar"])
 
 
 def test_sampler_and_apply_noise_bit_exact():
@@ -28,8 +36,10 @@ def test_sampler_and_apply_noise_bit_exact():
                                                  g[f"{mode}_expX"], g[f"{mode}_expE"])
         assert torch.equal(Xt, g[f"{mode}_X_t"]) and torch.equal(Et, g[f"{mode}_E_t"])
         assert torch.equal(Xc, g[f"{mode}_Xc"]) and torch.equal(Ec, g[f"{mode}_Ec"])
-        for k in ("t", "beta_t", "alpha_s_bar", "alpha_t_bar"):
+        for k in ("t", "beta_t"):
             assert torch.equal(npar[k], g[f"{mode}_{k}"])
+        for k in ("alpha_s_bar", "alpha_t_bar"):
+            _ulp_close(npar[k], g[f"{mode}_{k}"])
     lX, lE = O_dif.sample_limit(g["mx"], g["me"], mask, g["lim_expX"], g["lim_expE"])
     assert torch.equal(lX, g["lim_X"]) and torch.equal(lE, g["lim_E"])
 
@@ -114,7 +124,7 @@ def test_posteriors_and_elbo_terms():
     pb = O_dif.posterior_over_x0(g["X_t"], O_dif.Qt(noise["beta_t"], mx), O_dif.Qt_bar(noise["alpha_s_bar"], mx),
                                  O_dif.Qt_bar(noise["alpha_t_bar"], mx))
     assert_close(pb, g["post_over0_X"])
-    assert_close(O_dif.kl_prior(O_dif.Schedule(500), mx, me, g["X"], g["E"], mask), g["kl_prior"])
+    assert_close(O_dif.kl_prior(O_dif.Schedule(500), mx, me, g["X"], g["E"], mask), g["kl_prior"], atol=2e-6)   # zero in exact arithmetic at T = 500: absolute bound
     *_, Lt = O_dif.compute_Lt_terms(500, mx, me, g["X"], g["E"], g["X_t"], g["E_t"], g["logits_X"], g["logits_E"], mask, noise)
     assert_close(Lt, g["Lt"])
     pX, pE = O_dif.reverse_step_probs(g["logits_X"], g["logits_E"], g["X_t"], g["E_t"], noise["beta_t"],
@@ -200,7 +210,7 @@ def test_validation_elbo_step():
         nll, parts = O_dif.val_nll(sch, mx, me, hist, g["X"], g["E"], X_t, E_t, lX, lE, mask, npar, pX0, pE0)
     assert_close(nll, g["nll"], rtol=2e-5, what="NLL"); assert_close(parts["Lt"], g["Lt"], rtol=2e-5, what="Lt")
     assert_close(parts["loss_term_0"], g["loss_term_0"], rtol=2e-5, what="t=0 term")
-    assert_close(parts["kl_prior"].mean(), g["kl_prior"], what="KL prior"); assert_close(parts["log_pN"].mean(), g["log_pn"], what="log pN")
+    assert_close(parts["kl_prior"].mean(), g["kl_prior"], atol=2e-6, what="KL prior (zero in exact arithmetic)"); assert_close(parts["log_pN"].mean(), g["log_pn"], what="log pN")
     assert_close(nll, g["epoch_NLL"], rtol=2e-5, what="epoch NLL (single batch)")
 
 
