@@ -60,6 +60,16 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
 int mbvae_linear_bwd_input_add(const float* dy, int64_t lddy, const float* w, const float* addend, float* dx,
                                int64_t lddx, int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
                                const uint8_t* mask, int mask_mode, int n_nodes, mbvae_stream_t stream);
+/* y[M,64] = LayerNorm(z) * gamma + beta with z[M,64] = resid + dropout_p(rowmask(x[M,K] @ w[64,K]^T + bias)): a Linear with a
+ * 64-wide output and the residual LayerNorm that consumes it in ONE kernel - `E = normE1(E + dropoutE1(newE))` after
+ * e_out (graph_transformer.py:123-130 with the masked e_out of :255-258) and `E = normE2(E + dropoutE3(linE2(.)))`
+ * (graph_transformer.py:139-146).  z is kept for mbvae_ln_sum_bwd; the Linear's own gradients then come from the usual
+ * mbvae_linear_bwd_* calls on that kernel's dr.  Dropout mask: that of mbvae_ln_residual_fwd for (seed, element index).
+ * Only N == 64, K % 64 == 0, K <= 384, M >= 8192, M % 32 == 0; MBVAE_EUNSUPPORTED otherwise (run the two separately). */
+int mbvae_linear_ln_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* resid,
+                        const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                        const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                        mbvae_stream_t stream);
 /* dx[M,K] = out_gate[M,K] > 0 ? (rowmask(dy)[M,N] @ w[N,K]) * out_gate_scale : 0.  out_gate is this layer's INPUT when that
  * input came out of ReLU (+ dropout) - linE2 / linX2 / lin_y2 of the feed-forward blocks, graph_transformer.py:139-146 -:
  * the gate of the layer below is applied where the gradient is produced, and that layer's gradient calls take gate = NULL. */
@@ -186,6 +196,13 @@ int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, co
                           const float* dy, float* dx, float* dr, float* dgamma, float* dbeta, int64_t rows,
                           int64_t D, float drop_p, uint64_t seed, void* workspace, int64_t ws_bytes,
                           mbvae_stream_t stream);
+
+/* Backward of the LayerNorm inside mbvae_linear_ln_fwd (torch.nn.LayerNorm backward of graph_transformer.py:130,146 plus
+ * the dropout of :128,144): z is the stored pre-LayerNorm sum; dx = gradient of the residual operand, dr = dx * dropout
+ * scale = gradient of the Linear's output (null: not wanted), dgamma, dbeta.  Row statistics are recomputed from z. */
+int mbvae_ln_sum_bwd(const float* z, const float* gamma, const float* dy, float* dx, float* dr, float* dgamma,
+                     float* dbeta, int64_t rows, int64_t D, float eps, float drop_p, uint64_t seed, void* workspace,
+                     int64_t ws_bytes, mbvae_stream_t stream);
 
 /* ---- X->y / E->y pooling ---------------------------------------------------------------------------
  * Replaces Xtoy / Etoy statistics, graph_transformer.py:40-46,57-65: x [bs,L,D] -> [bs,4D] = mean|min|max|

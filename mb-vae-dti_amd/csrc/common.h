@@ -47,13 +47,15 @@ enum MbvaeOption {
   MBVAE_OPT_NO_FFN_HANDOVER,   // feed-forward blocks: the ReLU gate stays inside the first Linear's gradient kernels (read by the host side)
   MBVAE_OPT_NO_FILM,       // node update: the torch expression instead of the FiLM kernel pair (read by the host side)
   MBVAE_OPT_NO_BWD_BOTH,   // e_mul|e_add projection: separate input- and weight-gradient kernels instead of the single pass over dY
+  MBVAE_OPT_NO_LN_EPILOGUE, // 64-wide edge Linears feeding a residual LayerNorm: separate Linear and LayerNorm kernels instead of the fused epilogue
   MBVAE_OPT_COUNT
 };
 inline const char* const* mbvae_option_names() {
   static const char* const names[MBVAE_OPT_COUNT] = {"NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64", "NO_TSWGRAD", "NO_TSWGRAD2",
                                                      "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
                                                      "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE", "NO_SPLIT_MFMA",
-                                                     "NO_E12_RECOMPUTE", "EFB_SYNC", "EF_STAGGER", "NO_COLGROUPS", "NO_EF_COOP", "NO_EFB_COOP", "NO_FFN_HANDOVER", "NO_FILM", "NO_BWD_BOTH"};
+                                                     "NO_E12_RECOMPUTE", "EFB_SYNC", "EF_STAGGER", "NO_COLGROUPS", "NO_EF_COOP", "NO_EFB_COOP", "NO_FFN_HANDOVER", "NO_FILM", "NO_BWD_BOTH",
+                                                     "NO_LN_EPILOGUE"};
   return names;
 }
 struct MbvaeOptions {

@@ -52,7 +52,21 @@ struct GemmArgs {
   int a_bf16, b_bf16, c_bf16;
   // wave-autonomous tall-skinny kernel only: columns per workgroup column group (blockIdx.y picks the group); 0 = all N
   int col_group;
+  // LayerNorm epilogue of the wave-autonomous kernel (N == 64): z = addend + dropout(rowmask(x W^T + b)) goes to ln_z
+  // and LayerNorm(z) * ln_gamma + ln_beta to C
+  const float* ln_gamma; const float* ln_beta; float* ln_z; float ln_eps;
 };
+
+// Sum over the 32 lanes of a half-wave (every lane receives it): four DPP steps inside each row of 16 lanes
+// (two quad permutes, half-row mirror, row mirror) and one swizzle that pairs the two rows of the half.
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));                     // lane ^ 16
+  return v;
+}
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col, float keep_row) {
   if (g.bias) v += g.bias[col];
@@ -482,8 +496,14 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 // its B octets as well, right after reading them - more vector work per MFMA, still ahead of the fp32 MFMA.
 // ABF / CBF: A is read / C is written as bf16 (the opt-in bf16 storage of the large edge activations).  A bf16 operand
 // IS its own hi plane, so its products need three MFMAs instead of six.
-template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false, bool CGATE = false>
+// LNE: residual + dropout + LayerNorm in the epilogue (TN == 2 and N == 64: a wave's task is 32 whole rows).  In the
+// accumulator layout a row's 64 values sit in the 32 lanes of one half-wave (two per lane), 16 rows per lane: the two
+// row statistics are half-wave sums (mean first, then the centred squares - the two-pass form of the stand-alone
+// LayerNorm kernel).  The pre-LayerNorm sum z is stored next to the output for the backward pass.
+template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false, bool CGATE = false,
+          bool LNE = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
+  static_assert(!LNE || (TN == 2 && ADD && !CBF && !CGATE && !ABF), "the LayerNorm epilogue: 64-wide fp32 rows with a residual operand");
   static_assert(!(ABF && (GATE || SPLIT == 0)), "a bf16 A operand runs on the bf16 pipeline and has no gate");
   static_assert(!(ADD && CGATE) && !(CGATE && CBF), "an output gate comes without an addend and with fp32 output");
   constexpr int NP = ABF ? 4 : 8;                  // 16-byte words of A per lane and 64-wide reduction group
@@ -562,6 +582,10 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rsrcC =
       __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * CS), 0x00020000);
   const int voffC = (int)((4u * h * ldc + r) * CS);      // byte offset of (row 4h, column r) inside a task's tile
+  const __amdgpu_buffer_rsrc_t rsrcZ =
+      __builtin_amdgcn_make_buffer_rsrc(LNE ? g.ln_z : g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * CS), 0x00020000);
+  float lng[2] = {1.f, 1.f}, lnb[2] = {0.f, 0.f};        // LayerNorm scale / shift of this lane's two columns
+  if (LNE) { lng[0] = g.ln_gamma[r]; lng[1] = g.ln_gamma[32 + r]; lnb[0] = g.ln_beta[r]; lnb[1] = g.ln_beta[32 + r]; }
 
 #define TS2_TASK(qq, lt, gi, tile, cb)                                                                \
     const int lt = (qq) / gpt, gi = (qq) - lt * gpt;                                                   \
@@ -699,7 +723,37 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
       const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * CS;   /* wave-uniform byte offset */ \
       float bn[TN];                                                                                    \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = bjr[1 - S][j] * has_bias;                 \
-      if (ADD || CGATE) {                              /* all addend / gate loads first, then one wait */ \
+      if (LNE) {                                       /* residual + dropout + LayerNorm over the task's 32 whole rows */ \
+        const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + r;                               \
+        float zz[2][16], mu[16], rs[16];                                                               \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v)                                                 \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+            zz[j][v] = g.addend[off0 + (unsigned)((v & 3) + 8 * (v >> 2)) * ldc + j * 32];             \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          const bool kr = (kh >> rr) & 1u;                                                             \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+            float o = kr ? acc[j % TN][v] : 0.f;                                                       \
+            if (drop) o *= mbvae_u01(g.seed, off0 + (unsigned)rr * ldc + j * 32) < g.drop_p ? 0.f : drop_keep; \
+            zz[j][v] += o;                                                                             \
+          }                                                                                            \
+          mu[v] = zz[0][v] + zz[1][v];                                                                 \
+        }                                                                                              \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) mu[v] = half_wave_sum(mu[v]) * (1.f / 64.f);    \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const float d0 = zz[0][v] - mu[v], d1 = zz[1][v] - mu[v];                                    \
+          rs[v] = d0 * d0 + d1 * d1;                                                                   \
+        }                                                                                              \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) rs[v] = rsqrtf(half_wave_sum(rs[v]) * (1.f / 64.f) + g.ln_eps); \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                               \
+          const int rr = (v & 3) + 8 * (v >> 2);                                                       \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+            const int so_ = (int)(sbase + ((unsigned)rr * ldc + j * 32) * 4u);                         \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zz[j][v]), rsrcZ, voffC, so_, TS2_AUX); \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((zz[j][v] - mu[v]) * rs[v] * lng[j] + lnb[j]), rsrcC, voffC, so_, 0); \
+          }                                                                                            \
+        }                                                                                              \
+      } else if (ADD || CGATE) {                       /* all addend / gate loads first, then one wait */ \
         const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + cb * (32 * TN) + r;              \
         const float* adp = CGATE ? g.c_gate : g.addend;                                                \
         float ad[TN][16];                                                                              \
@@ -1949,6 +2003,39 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
   g.a_gate = gate; g.a_gate_scale = gate_scale; g.mask = mask; g.a_mask_mode = mask_mode; g.n_nodes = n_nodes;
   g.accumulate = accumulate;
   return gemm_dispatch<true, false>(g, workspace, ws_bytes, stream);
+}
+
+// y[M,64] = LayerNorm(z) * gamma + beta,  z[M,64] = resid + dropout_p(mask_rows(x[M,K] @ w[64,K]^T + bias)): a Linear whose
+// 64-wide output feeds a residual LayerNorm (e_out -> normE1, linE2 -> normE2) with the normalisation in the product's
+// epilogue, so the Linear's output never travels through memory; z is kept for mbvae_ln_sum_bwd.  The dropout mask is
+// the one mbvae_ln_residual_fwd would draw for (seed, element index).  MBVAE_EUNSUPPORTED for shapes the wave-autonomous
+// tall-skinny kernel does not take (run the Linear and mbvae_ln_residual_fwd separately then).
+int mbvae_linear_ln_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* resid,
+                        const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                        const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                        hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!x || !w || !resid || !gamma || !beta || !y || !z || M <= 0) return MBVAE_EINVAL;
+  if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
+  if (mbvae_opt(MBVAE_OPT_NO_TSGEMM) || mbvae_opt(MBVAE_OPT_NO_TSGEMM2) || mbvae_opt(MBVAE_OPT_NO_LN_EPILOGUE)) return MBVAE_EUNSUPPORTED;
+  if (N != 64 || K % 64 || K <= 0 || K > 512 || M % 32 || M < 8192 || M * 64 >= 0x3fffffff) return MBVAE_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)resid | (uintptr_t)y | (uintptr_t)z) & 15) || (ldx & 3)) return MBVAE_EUNSUPPORTED;
+  GemmArgs g = {};
+  g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = 64; g.K = (int)K;
+  g.lda = ldx; g.ldb = K; g.ldc = 64;
+  g.a_gate_scale = 1.f; g.mask = mask; g.c_mask_mode = mask_mode; g.n_nodes = n_nodes;
+  g.bias = bias; g.drop_p = drop_p; g.seed = seed;
+  g.addend = resid; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_z = z; g.ln_eps = eps;
+  const size_t smem3 = 2 * 3 * (size_t)64 * (K + 8), smemf = sizeof(float) * (size_t)K * 65;
+  const bool split1 = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && smem3 <= MBVAE_LDS_LIMIT;
+  const size_t smem = split1 ? smem3 : smemf;
+  if (smem > MBVAE_LDS_LIMIT) return MBVAE_EUNSUPPORTED;
+  auto ks = tsgemm2_kernel<2, true, false, 8, true, 1, false, false, false, true>;
+  auto kf = tsgemm2_kernel<2, true, false, 8, true, 0, false, false, false, true>;
+  if (!(split1 ? MBVAE_ALLOW_BIG_LDS(ks) : MBVAE_ALLOW_BIG_LDS(kf))) return MBVAE_ELAUNCH;
+  const int grid = std::min(std::max((int)(M / 256), 1), ts_num_cus());
+  hipLaunchKernelGGL(split1 ? ks : kf, dim3(grid), dim3(512), smem, stream, g);
+  return mbvae_launch_status();
 }
 
 // dx[M,K] = pro(dy)[M,N] @ w[N,K] + addend[M,K] (addend laid out like dx).  Only shapes served by the persistent

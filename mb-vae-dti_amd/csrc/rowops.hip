@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                          const float* __restrict__ rstd_in, const float* __restrict__ dy,
                                                          float* __restrict__ dx, float* __restrict__ dr,
-                                                         float* __restrict__ part, int64_t rows, float drop_p, uint64_t seed) {
+                                                         float* __restrict__ part, int64_t rows, float drop_p, uint64_t seed,
+                                                         float eps) {
+  // mean_in == null: x already IS the pre-LayerNorm sum z (r is null then) and the row statistics are recomputed
+  // from it, in the forward's two-pass form; dr = dz * dropout scale is still written for the branch that was added.
   constexpr int D = LPR * 4 * VPL;
   constexpr int GROUPS = 256 / LPR;
   __shared__ float red[2 * 256 * 4];
@@ -91,49 +94,92 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict
     gm[v] = ld4(gamma + (v * LPR + sub) * 4);
     dg[v] = make_float4(0.f, 0.f, 0.f, 0.f); db[v] = dg[v];
   }
-  for (int64_t row = (int64_t)blockIdx.x * GROUPS + grp; row < rows; row += (int64_t)gridDim.x * GROUPS) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float4 xh[VPL], g[VPL];
-    float s1 = 0.f, s2 = 0.f;
+  // Narrow rows (one 16-byte word per lane) take two rows per trip, every load of both issued before the first use:
+  // with two or three streams of 16 bytes per lane the kernel is otherwise short of bytes in flight.
+  constexpr int UNR = VPL == 1 ? 2 : 1;
+  const int64_t stride = (int64_t)gridDim.x * GROUPS;
+  for (int64_t row0 = (int64_t)blockIdx.x * GROUPS + grp; row0 < rows; row0 += stride * UNR) {
+    float4 zz[UNR][VPL], dd[UNR][VPL];
+    float mean[UNR], rstd[UNR];
+    bool ok[UNR];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int64_t off = row * D + (v * LPR + sub) * 4;
-      float4 z = ld4(x + off);
-      if (r) {
-        const float4 t = ld4(r + off);
-        if (drop_p > 0.f) {
-          z.x += t.x * mbvae_drop_scale(drop_p, seed, off + 0);
-          z.y += t.y * mbvae_drop_scale(drop_p, seed, off + 1);
-          z.z += t.z * mbvae_drop_scale(drop_p, seed, off + 2);
-          z.w += t.w * mbvae_drop_scale(drop_p, seed, off + 3);
-        } else { z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w; }
-      }
-      const float4 d = ld4(dy + off);
-      xh[v] = make_float4((z.x - mean) * rstd, (z.y - mean) * rstd, (z.z - mean) * rstd, (z.w - mean) * rstd);
-      g[v] = make_float4(d.x * gm[v].x, d.y * gm[v].y, d.z * gm[v].z, d.w * gm[v].w);
-      s1 += (g[v].x + g[v].y) + (g[v].z + g[v].w);
-      s2 += (g[v].x * xh[v].x + g[v].y * xh[v].y) + (g[v].z * xh[v].z + g[v].w * xh[v].w);
-      dg[v].x += d.x * xh[v].x; dg[v].y += d.y * xh[v].y; dg[v].z += d.z * xh[v].z; dg[v].w += d.w * xh[v].w;
-      db[v].x += d.x; db[v].y += d.y; db[v].z += d.z; db[v].w += d.w;
-    }
-    const float m1 = group_sum<LPR>(s1) * (1.f / D), m2 = group_sum<LPR>(s2) * (1.f / D);
+    for (int u = 0; u < UNR; ++u) {
+      ok[u] = row0 + u * stride < rows;
+      const int64_t row = ok[u] ? row0 + u * stride : row0;      // (a row past the end re-reads row0; nothing of it is kept)
+      if (mean_in) { mean[u] = mean_in[row]; rstd[u] = rstd_in[row]; }
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int64_t off = row * D + (v * LPR + sub) * 4;
-      float4 dz;
-      dz.x = rstd * (g[v].x - m1 - xh[v].x * m2);
-      dz.y = rstd * (g[v].y - m1 - xh[v].y * m2);
-      dz.z = rstd * (g[v].z - m1 - xh[v].z * m2);
-      dz.w = rstd * (g[v].w - m1 - xh[v].w * m2);
-      st4(dx + off, dz);
-      if (dr) {
-        if (drop_p > 0.f) {
-          dz.x *= mbvae_drop_scale(drop_p, seed, off + 0);
-          dz.y *= mbvae_drop_scale(drop_p, seed, off + 1);
-          dz.z *= mbvae_drop_scale(drop_p, seed, off + 2);
-          dz.w *= mbvae_drop_scale(drop_p, seed, off + 3);
+      for (int v = 0; v < VPL; ++v) {
+        const int64_t off = row * D + (v * LPR + sub) * 4;
+        zz[u][v] = ld4(x + off);
+        dd[u][v] = ld4(dy + off);
+        if (r) {
+          const float4 t = ld4(r + off);
+          if (drop_p > 0.f) {
+            zz[u][v].x += t.x * mbvae_drop_scale(drop_p, seed, off + 0);
+            zz[u][v].y += t.y * mbvae_drop_scale(drop_p, seed, off + 1);
+            zz[u][v].z += t.z * mbvae_drop_scale(drop_p, seed, off + 2);
+            zz[u][v].w += t.w * mbvae_drop_scale(drop_p, seed, off + 3);
+          } else { zz[u][v].x += t.x; zz[u][v].y += t.y; zz[u][v].z += t.z; zz[u][v].w += t.w; }
         }
-        st4(dr + off, dz);
+      }
+    }
+    if (!mean_in) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) s += (zz[u][v].x + zz[u][v].y) + (zz[u][v].z + zz[u][v].w);
+        mean[u] = group_sum<LPR>(s) * (1.f / D);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const float a = zz[u][v].x - mean[u], b = zz[u][v].y - mean[u], c = zz[u][v].z - mean[u], d = zz[u][v].w - mean[u];
+          q += (a * a + b * b) + (c * c + d * d);
+        }
+        rstd[u] = rsqrtf(group_sum<LPR>(q) * (1.f / D) + eps);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t row = ok[u] ? row0 + u * stride : row0;
+      const float keep = ok[u] ? 1.f : 0.f;
+      float4 xh[VPL], g[VPL];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float4 z = zz[u][v], d = dd[u][v];
+        xh[v] = make_float4((z.x - mean[u]) * rstd[u], (z.y - mean[u]) * rstd[u], (z.z - mean[u]) * rstd[u], (z.w - mean[u]) * rstd[u]);
+        g[v] = make_float4(d.x * gm[v].x, d.y * gm[v].y, d.z * gm[v].z, d.w * gm[v].w);
+        s1 += (g[v].x + g[v].y) + (g[v].z + g[v].w);
+        s2 += (g[v].x * xh[v].x + g[v].y * xh[v].y) + (g[v].z * xh[v].z + g[v].w * xh[v].w);
+        if (UNR == 1) {
+          dg[v].x += d.x * xh[v].x; dg[v].y += d.y * xh[v].y; dg[v].z += d.z * xh[v].z; dg[v].w += d.w * xh[v].w;
+          db[v].x += d.x; db[v].y += d.y; db[v].z += d.z; db[v].w += d.w;
+        } else {                                   // a row past the end contributes nothing
+          dg[v].x += keep * d.x * xh[v].x; dg[v].y += keep * d.y * xh[v].y; dg[v].z += keep * d.z * xh[v].z; dg[v].w += keep * d.w * xh[v].w;
+          db[v].x += keep * d.x; db[v].y += keep * d.y; db[v].z += keep * d.z; db[v].w += keep * d.w;
+        }
+      }
+      const float m1 = group_sum<LPR>(s1) * (1.f / D), m2 = group_sum<LPR>(s2) * (1.f / D);
+      if (ok[u]) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int64_t off = row * D + (v * LPR + sub) * 4;
+          float4 dz;
+          dz.x = rstd[u] * (g[v].x - m1 - xh[v].x * m2);
+          dz.y = rstd[u] * (g[v].y - m1 - xh[v].y * m2);
+          dz.z = rstd[u] * (g[v].z - m1 - xh[v].z * m2);
+          dz.w = rstd[u] * (g[v].w - m1 - xh[v].w * m2);
+          st4(dx + off, dz);
+          if (dr) {
+            if (drop_p > 0.f) {
+              dz.x *= mbvae_drop_scale(drop_p, seed, off + 0);
+              dz.y *= mbvae_drop_scale(drop_p, seed, off + 1);
+              dz.z *= mbvae_drop_scale(drop_p, seed, off + 2);
+              dz.w *= mbvae_drop_scale(drop_p, seed, off + 3);
+            }
+            st4(dr + off, dz);
+          }
+        }
       }
     }
   }
@@ -207,7 +253,7 @@ static int ln_launch(bool fwd, const float* x, const float* r, const float* gamm
     if (part_floats < blocks * 2 * D) blocks = part_floats / (2 * D);
     if (blocks < 1) return MBVAE_EINVAL;
     hipLaunchKernelGGL((ln_res_bwd_kernel<LPR, VPL>), dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean,
-                       rstd, dy, dx, dr, part, rows, drop_p, seed);
+                       rstd, dy, dx, dr, part, rows, drop_p, seed, eps);
     // part is [blocks][2][D]: view as [blocks][2D] and sum -> dgamma | dbeta
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, part, dgamma, dbeta, (int)blocks, 2 * D, D);
   }
@@ -596,6 +642,21 @@ int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, co
   hipLaunchKernelGGL(ln_res_bwd_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean, rstd, dy,
                      dx, dr, dgamma, dbeta, rows, (int)D, drop_p, seed);
   return mbvae_launch_status();
+}
+
+// Backward of y = LayerNorm(z) * gamma + beta where z = x + dropout_p(r) was formed and stored by the producer
+// (mbvae_linear_ln_fwd): dx = dz (gradient of the residual operand), dr = dz * dropout scale of (seed, element index)
+// (gradient of the Linear's output; may be null), dgamma, dbeta.  The row statistics are recomputed from z.
+// Widths of the vectorised kernel only (16 ... 2048, see ln_dispatch).
+int mbvae_ln_sum_bwd(const float* z, const float* gamma, const float* dy, float* dx, float* dr, float* dgamma,
+                     float* dbeta, int64_t rows, int64_t D, float eps, float drop_p, uint64_t seed, void* workspace,
+                     int64_t ws_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (!z || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0) return MBVAE_EINVAL;
+  const int64_t floats = ws_bytes / (int64_t)sizeof(float) - 2 * D;
+  if (floats < 2 * D) return MBVAE_EINVAL;
+  return ln_dispatch(false, D, z, nullptr, gamma, nullptr, nullptr, nullptr, nullptr, dy, dx, dr, dgamma, dbeta,
+                     (float*)workspace, floats, rows, eps, drop_p, seed, stream);
 }
 
 // x [bs,L,D] -> stats [bs,4D] (mean|min|max|std), arg [bs,2,D] int32 (first argmin / argmax along L)

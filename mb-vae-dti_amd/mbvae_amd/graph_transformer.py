@@ -84,7 +84,8 @@ class NodeEdgeBlock(nn.Module):
         w, b = self._stacked(key, layers)
         return ops.linear(x, w, b, **kw)
 
-    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None, pack=None):
+    def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None, pack=None,
+                edge_norm_train=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
         use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input).
         pack (ops.NodePack, inference only): X and newX are packed node rows [rows, dx] instead of [bs, n, dx]."""
@@ -109,7 +110,15 @@ class NodeEdgeBlock(nn.Module):
         else:
             if not P.requires_grad:         # exactly when the no-gradient attention forward ran: it skips padding pairs
                 ops.zero_masked_pairs_(P, node_mask)
-            newE = _lin(self.e_out, P, **edge)
+            if edge_norm_train is not None and ops.linear_ln_supported(P, self.e_out.weight, E_alias):
+                # training: e_out with the layer's first edge LayerNorm (residual + dropout) in its epilogue; the caller
+                # sees the flag on the block and skips its own normE1
+                ln, eps, p, seed = edge_norm_train
+                newE = ops.linear_ln(P, self.e_out.weight, self.e_out.bias, E_alias, ln.weight, ln.bias, eps, p, seed, **edge)
+                self.__dict__["_edge_normed"] = True
+            else:
+                newE = _lin(self.e_out, P, **edge)
+                self.__dict__["_edge_normed"] = False
         if pack is not None:
             film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
         elif torch.is_grad_enabled():
@@ -149,23 +158,31 @@ class XEyTransformerLayer(nn.Module):
         p = self.dropout_p if self.training else 0.0
         seeds = seeds or _SeedStream(p > 0)
         inference = p == 0.0 and not torch.is_grad_enabled()      # sampling / validation
+        # dropout seeds in the order the three first norms use them (X, y, E), drawn before the attention block because
+        # the edge norm may run inside it
+        sX1, sy1, sE1 = seeds.next(), seeds.next(), seeds.next()
         newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
                                               edge_norm=(self.normE1, self.eps) if inference else None,
                                               tile_map=tile_map if inference else None,
                                               order=order if inference else None,
-                                              pack=pack if inference else None)
+                                              pack=pack if inference else None,
+                                              edge_norm_train=None if inference else (self.normE1, self.eps, p, sE1))
 
-        def norm(ln, x, r):
-            return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next())
+        def norm(ln, x, r, seed=None):
+            return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next() if seed is None else seed)
 
-        X, y = norm(self.normX1, X, newX), norm(self.norm_y1, y, new_y)
-        E = newE if inference else norm(self.normE1, E, newE)      # (inference: newE already is normE1(E + e_out(.)))
+        X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
+        # (inference, or training with the fused epilogue: newE already is normE1(E + dropout(e_out(.))))
+        E = newE if (inference or self.self_attn.__dict__.get("_edge_normed")) else norm(self.normE1, E, newE, sE1)
 
         def ff_block(ln, l1, l2, x):
             """norm(x + dropout(l2(dropout(relu(l1(x)))))); the residual branch uses l1's alias of x so that both
-            gradients of x meet inside l1's input-gradient product."""
-            out, x = ops.ffn(x, l1.weight, l1.bias, l2.weight, l2.bias, drop_p=p, seed=seeds.next())
-            return norm(ln, x, out)
+            gradients of x meet inside l1's input-gradient product.  Where the second Linear takes the LayerNorm into
+            its epilogue (the edge tensor) ffn returns the normalised result itself."""
+            s_ffn, s_norm = seeds.next(), seeds.next()
+            out, x = ops.ffn(x, l1.weight, l1.bias, l2.weight, l2.bias, drop_p=p, seed=s_ffn,
+                             ln=(ln.weight, ln.bias, self.eps, p, s_norm))
+            return out if x is None else norm(ln, x, out, s_norm)
 
         X = ff_block(self.normX2, self.linX1, self.linX2, X)
         if inference:                                     # the edge feed-forward block in one pass

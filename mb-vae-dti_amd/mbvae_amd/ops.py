@@ -191,21 +191,23 @@ def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=
     return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias, in_gate_scale, pregated)
 
 
-def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None):
+def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None, ln=None):
     """(l2(dropout(relu(l1(x)))), alias of x for the residual branch): the two Linears of a feed-forward block
     (graph_transformer.py:139-146).  The hidden activation h has exactly one consumer, so with `handover` the ReLU /
     dropout gate of l1 is applied by l2's backward where it produces dh (h itself is the gate) and l1's two gradient
     kernels read the gated dh without loading h again: 0.5 KB less traffic per row.  Default: on for the edge path
     (>= 32768 rows), where the gate sits in the product's epilogue; the short node / global paths keep the gate inside
-    l1's kernels (one launch fewer)."""
+    l1's kernels (one launch fewer).
+    ln = (gamma, beta, eps, drop_p, seed) of the residual LayerNorm that follows: where l2 can take it into its epilogue
+    (linear_ln_supported) the result is (LayerNorm(x + dropout(l2(.))), None) - the block is finished."""
     if handover is None:
         handover = x.numel() // x.shape[-1] >= 32768 and not option_set("NO_FFN_HANDOVER")
-    if not handover:
-        h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True)
-        return linear(h, w2, b2), xa
     scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
-    h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True, pregated=True)
-    return linear(h, w2, b2, in_gate_scale=scale), xa
+    h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True, pregated=handover)
+    if ln is not None and linear_ln_supported(h, w2, xa):
+        gamma, beta, eps, p2, seed2 = ln
+        return linear_ln(h, w2, b2, xa, gamma, beta, eps, p2, seed2, in_gate_scale=scale if handover else None), None
+    return linear(h, w2, b2, in_gate_scale=scale if handover else None), xa
 
 
 # ------------------------------------------------------------------------------------------------ edge-tensor fan-out
@@ -520,6 +522,75 @@ class _LnResidual(torch.autograd.Function):
         if r is not None and dr is None:
             dr = dx          # no dropout: the residual branch receives the same gradient
         return dx, dr, dgamma, dbeta, None, None, None
+
+
+class _LinearLn(torch.autograd.Function):
+    """LayerNorm(resid + dropout(rowmask(x @ W^T + b))) with the normalisation in the product's epilogue
+    (mbvae_linear_ln_fwd): the Linear's output never travels through memory and the backward reads ONE stored tensor
+    (the pre-LayerNorm sum) instead of the residual and the Linear's output.  The leading arguments are _Linear's, so
+    the Linear's own gradients come from _Linear.backward run on this node's dr."""
+
+    class _LinCtx:                       # what _Linear.backward reads from its ctx
+        pass
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, gamma, beta, mask, mask_mode, n_nodes, eps, drop_p, seed, in_gate_scale):
+        x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
+        w, resid, gamma, beta = _f32c(w, "weight"), _f32c(resid, "resid"), _f32c(gamma), _f32c(beta)
+        M, K = x2.shape
+        N = w.shape[0]
+        m8 = _mask_u8(mask)
+        y, z = torch.empty_like(resid), torch.empty_like(resid)
+        ok = _lib.call("mbvae_linear_ln_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), resid.data_ptr(), gamma.data_ptr(),
+                       beta.data_ptr(), y.data_ptr(), z.data_ptr(), M, K, N, _ptr(m8), mask_mode, n_nodes, float(eps),
+                       float(drop_p), int(seed), _stream(), tag=(M, K, N), allow_unsupported=True)
+        if not ok:
+            raise RuntimeError("mbvae_linear_ln_fwd does not take this shape (check linear_ln_supported first)")
+        ctx.save_for_backward(x2, w, m8, z, gamma)
+        ctx.cfg = (mask_mode, n_nodes, float(eps), float(drop_p), int(seed), b is not None, x.shape, in_gate_scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, m8, z, gamma = ctx.saved_tensors
+        mask_mode, n_nodes, eps, drop_p, seed, has_bias, xshape, in_gate_scale = ctx.cfg
+        D = z.shape[-1]
+        rows = z.numel() // D
+        dy = _f32c(dy, "dy")
+        dres = torch.empty_like(z)
+        need_lin = any(ctx.needs_input_grad[:3])
+        dr = torch.empty_like(z) if (drop_p > 0 and need_lin) else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = workspace(z.device)
+        _lib.call("mbvae_ln_sum_bwd", z.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dres.data_ptr(), _ptr(dr),
+                  dgamma.data_ptr(), dbeta.data_ptr(), rows, D, eps, drop_p, seed, ws.data_ptr(), ws.numel(), _stream())
+        dx = dw = db = None
+        if need_lin:
+            lin = _LinearLn._LinCtx()
+            lin.saved_tensors = (x2, w, None, m8)
+            lin.cfg = (mask_mode, n_nodes, 0.0, False, has_bias, xshape)
+            lin.in_gate_scale, lin.relu = in_gate_scale, False
+            lin.needs_input_grad = tuple(ctx.needs_input_grad[:3])
+            dx, dw, db = _Linear.backward(lin, dr if dr is not None else dres)[:3]
+        return dx, dw, db, dres, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def linear_ln_supported(x, weight, resid):
+    """Shapes mbvae_linear_ln_fwd takes: a 64-wide fp32 Linear over >= 8192 rows (the edge tensor's e_out and linE2)."""
+    M = x.numel() // x.shape[-1]
+    K = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.shape[0] == 64 and resid.shape[-1] == 64 and K % 64 == 0
+            and K <= 384 and M >= 8192 and M % 32 == 0 and M * 64 < 0x3fffffff
+            and not (option_set("NO_LN_EPILOGUE") or option_set("NO_TSGEMM") or option_set("NO_TSGEMM2")))
+
+
+def linear_ln(x, weight, bias, resid, gamma, beta, eps=1e-5, drop_p=0.0, seed=0, mask=None, mask_mode=MASK_NONE, n_nodes=0,
+              in_gate_scale=None):
+    """LayerNorm(resid + dropout(rowmask(x @ W^T + b))) * gamma + beta in one kernel; see linear_ln_supported.
+    in_gate_scale: as for linear() - x came out of a ReLU (+ dropout) layer whose gate this layer's backward applies."""
+    if mask is None:
+        mask_mode = MASK_NONE
+    return _LinearLn.apply(x, weight, bias, resid, gamma, beta, mask, mask_mode, n_nodes, eps, drop_p, seed, in_gate_scale)
 
 
 def ln_residual(x, r, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):

@@ -860,6 +860,60 @@ def test_ffn_gate_handover(ops, M, d, dff, default_routes):
         assert_close(a, b_, what=name + " hand-over vs in-layer gate")
 
 
+@pytest.mark.parametrize("bs,n,K,masked,drop_p", [(16, 64, 256, True, 0.0), (16, 64, 128, False, 0.0), (2, 64, 256, True, 0.0),
+                                                   (9, 64, 256, True, 0.1), (16, 32, 128, False, 0.1), (3, 64, 64, True, 0.25)])
+def test_linear_layernorm_epilogue(ops, bs, n, K, masked, drop_p, default_routes):
+    """ops.linear_ln (a 64-wide Linear with residual + dropout + LayerNorm in the product's epilogue, backward from the
+    stored pre-LayerNorm sum): values and all six gradients against plain torch without dropout, and against the
+    separate Linear + residual-LayerNorm kernels on the same dropout seed (identical masks) with it."""
+    g = torch.Generator().manual_seed(bs * 1000 + n + K)
+    M = bs * n * n
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(64, K, generator=g) / math.sqrt(K); b = torch.randn(64, generator=g) * 0.1
+    resid = torch.randn(bs, n, n, 64, generator=g)
+    gamma = 1 + 0.2 * torch.randn(64, generator=g); beta = 0.1 * torch.randn(64, generator=g)
+    cot = torch.randn(bs, n, n, 64, generator=g)
+    mask = ragged_mask(bs, n, g) if masked else None
+    kw = dict(mask=dev(mask), mask_mode=ops.MASK_EDGE, n_nodes=n) if masked else {}
+    seed = 12345
+
+    def run(fused):
+        ins = [t.clone().cuda().requires_grad_(True) for t in (x, w, b, resid, gamma, beta)]
+        _lib.PROFILE = {}
+        try:
+            if fused:
+                assert ops.linear_ln_supported(ins[0], ins[1], ins[3])
+                y = ops.linear_ln(ins[0], ins[1], ins[2], ins[3], ins[4], ins[5], 1e-5, drop_p, seed, **kw)
+            else:
+                r = ops.linear(ins[0], ins[1], ins[2], **kw).reshape(bs, n, n, 64)
+                y = ops.ln_residual(ins[3], r, ins[4], ins[5], 1e-5, drop_p, seed)
+            (y * cot.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            called = {name for name, _ in _lib.PROFILE}
+        finally:
+            _lib.PROFILE = None
+        return y.detach(), [t.grad for t in ins], called
+
+    names = ("dx", "dw", "db", "dresid", "dgamma", "dbeta")
+    y, grads, called = run(True)
+    assert {"mbvae_linear_ln_fwd", "mbvae_ln_sum_bwd"} <= called and "mbvae_ln_residual_fwd" not in called
+    y0, grads0, called0 = run(False)
+    assert "mbvae_linear_ln_fwd" not in called0
+    assert_close(y, y0, what="fused vs separate kernels")
+    for a, b_, name in zip(grads, grads0, names):
+        assert_close(a, b_, what=name + " fused vs separate kernels")
+    if drop_p == 0.0:
+        ref = [t.clone().requires_grad_(True) for t in (x, w, b, resid, gamma, beta)]
+        r = F.linear(ref[0], ref[1], ref[2]).reshape(bs, n, n, 64)
+        if masked:
+            r = r * (mask[:, :, None] & mask[:, None, :]).unsqueeze(-1)
+        yr = F.layer_norm(ref[3] + r, (64,), ref[4], ref[5], 1e-5)
+        (yr * cot).sum().backward()
+        assert_close(y, yr, what="output")
+        for got, t, name in zip(grads, ref, names):
+            assert_close(got, t.grad, what=name)
+
+
 @pytest.mark.parametrize("bs,n,with_add,ragged", [(16, 64, True, True), (9, 64, False, True), (32, 32, True, False)])
 def test_projection_backward_single_pass(ops, bs, n, with_add, ragged, default_routes):
     """mbvae_linear_bwd_both (input gradient, weight gradient and bias gradient of the 64 -> 512 projection from one
