@@ -201,7 +201,7 @@ def main():
                 if tag is not None:
                     ms = sum(a.elapsed_time(b) for a, b in evs)
                     shapes[(name, tag)] = (ms, len(evs))
-            for (name, tag), (ms, calls) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:24]:
+            for (name, tag), (ms, calls) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
                 M, K, N = tag
                 print(f"  {name[6:]:18s} M={M:<8d} K={K:<5d} N={N:<5d} {ms / args.steps:8.3f} ms/step {calls // args.steps:4d} calls  "
                       f"{linear_flops(name, tag) * calls / (ms * 1e-3) / 1e12:6.1f} TFLOP/s", file=sys.stderr)

@@ -1876,11 +1876,250 @@ static int smallm_try(const GemmArgs& g, hipStream_t stream) {
   return mbvae_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Thin products: Linear layers over the pair rows with a handful of input or output features (the 5 bond classes at
+// either end of the edge MLPs: 5 -> 128 and 128 -> 5).  They are pure streams - 0.5 GB of the wide operand per call
+// against a few multiply-adds per element - that the tiled matrix-core kernels run at a tenth of the memory rate
+// (their tiles are 32 wide in every dimension).  Here a group of W/4 lanes owns a row of the wide operand (16 bytes per
+// lane), the thin operand's few values per row are broadcast loads, everything is plain fp32 FMA in k order, and two
+// rows per lane are in flight.
+template <int LPR>                                        // sum over aligned groups of LPR = 16, 32 or 64 lanes (DPP, see half_wave_sum)
+__device__ __forceinline__ float thin_group_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  if (LPR >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // lane ^ 16
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// out[m, n] = act(bias[n] + sum_{k < KT} A[m, k] * B(k, n)),  B(k, n) = B_KC ? B[n * ldb + k] : B[k * ldb + n];  N = 4 * LPR
+template <int KT, bool B_KC>
+__global__ __launch_bounds__(256) void thin_in_kernel(GemmArgs g) {
+  const int lpr = g.N >> 2, sub = threadIdx.x % lpr, grp = threadIdx.x / lpr, groups = 256 / lpr;
+  float4 w[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    if (B_KC) w[k] = make_float4(g.B[(int64_t)(4 * sub) * g.ldb + k], g.B[(int64_t)(4 * sub + 1) * g.ldb + k],
+                                 g.B[(int64_t)(4 * sub + 2) * g.ldb + k], g.B[(int64_t)(4 * sub + 3) * g.ldb + k]);
+    else w[k] = *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + 4 * sub);
+  }
+  const float4 b4 = g.bias ? *reinterpret_cast<const float4*>(g.bias + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool relu = g.act == 1;
+  const int64_t stride = (int64_t)gridDim.x * groups;
+  for (int64_t row0 = (int64_t)blockIdx.x * groups + grp; row0 < g.M; row0 += 2 * stride) {
+    float a[2][KT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = min(row0 + u * stride, (int64_t)g.M - 1);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) a[u][k] = g.A[row * g.lda + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = row0 + u * stride;
+      if (row < g.M) {
+        float4 o = b4;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          o.x = fmaf(a[u][k], w[k].x, o.x); o.y = fmaf(a[u][k], w[k].y, o.y);
+          o.z = fmaf(a[u][k], w[k].z, o.z); o.w = fmaf(a[u][k], w[k].w, o.w);
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(g.C + row * g.ldc + 4 * sub) = o;
+      }
+    }
+  }
+}
+
+// out[m, j] = act(bias[j] + sum_k A[m, k] * B[j * ldb + k]),  j < N <= 8,  K = 4 * LPR
+template <int LPR>
+__global__ __launch_bounds__(256) void thin_out_kernel(GemmArgs g) {
+  constexpr int GROUPS = 256 / LPR;
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  float4 w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    w[j] = j < g.N ? *reinterpret_cast<const float4*>(g.B + (int64_t)j * g.ldb + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bj = (g.bias && sub < g.N) ? g.bias[sub] : 0.f;
+  const bool relu = g.act == 1;
+  const int64_t stride = (int64_t)gridDim.x * GROUPS;
+  for (int64_t row0 = (int64_t)blockIdx.x * GROUPS + grp; row0 < g.M; row0 += 2 * stride) {
+    float4 x[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      x[u] = *reinterpret_cast<const float4*>(g.A + min(row0 + u * stride, (int64_t)g.M - 1) * g.lda + 4 * sub);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float o = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < g.N) {                                     // (uniform)
+          const float sj = thin_group_sum<LPR>((x[u].x * w[j].x + x[u].y * w[j].y) + (x[u].z * w[j].z + x[u].w * w[j].w));
+          o = sub == j ? sj : o;
+        }
+      const int64_t row = row0 + u * stride;
+      if (row < g.M && sub < g.N) {
+        o += bj;
+        g.C[row * g.ldc + sub] = relu ? fmaxf(o, 0.f) : o;
+      }
+    }
+  }
+}
+
+// Weight gradient of a thin layer: part[c][t] = sum_r wide[r, c] * thin[r, t] over this workgroup's rows, W = 4 * LPR wide
+// columns, T <= 8 thin ones; the wide operand optionally gated (ReLU gate of the layer's output).  WIDE_IS_A: the wide
+// operand is dY (A), the result is dW [W][T] and the column sums are the wide ones; otherwise the thin operand is dY,
+// the result dW [T][W] and the column sums the thin ones.  Partials per workgroup, summed by tswgrad_reduce_kernel.
+template <int LPR, bool WIDE_IS_A, int U>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(GemmArgs g) {
+  constexpr int GROUPS = 256 / LPR, W = 4 * LPR;
+  __shared__ float4 red[256];
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const float* wide = WIDE_IS_A ? g.A : g.B;
+  const float* thin = WIDE_IS_A ? g.B : g.A;
+  const int64_t ldw = WIDE_IS_A ? g.lda : g.ldb, ldt = WIDE_IS_A ? g.ldb : g.lda;
+  const int T = WIDE_IS_A ? g.N : g.M;
+  const float* gate = WIDE_IS_A ? g.a_gate : nullptr;
+  float4 acc[8], csw = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cst[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j] = make_float4(0.f, 0.f, 0.f, 0.f); cst[j] = 0.f; }
+  const int64_t R = g.K, stride = (int64_t)gridDim.x * GROUPS;
+  for (int64_t row0 = (int64_t)blockIdx.x * GROUPS + grp; row0 < R; row0 += U * stride) {
+    float4 wv[U], gv[U];
+    float t[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = min(row0 + u * stride, R - 1);
+      wv[u] = *reinterpret_cast<const float4*>(wide + row * ldw + 4 * sub);
+      if (gate) gv[u] = *reinterpret_cast<const float4*>(gate + row * ldw + 4 * sub);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[u][j] = j < T ? thin[row * ldt + j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 v = wv[u];
+      if (gate) {
+        v.x = gv[u].x > 0.f ? v.x * g.a_gate_scale : 0.f; v.y = gv[u].y > 0.f ? v.y * g.a_gate_scale : 0.f;
+        v.z = gv[u].z > 0.f ? v.z * g.a_gate_scale : 0.f; v.w = gv[u].w > 0.f ? v.w * g.a_gate_scale : 0.f;
+      }
+      if (row0 + u * stride >= R) v = make_float4(0.f, 0.f, 0.f, 0.f);     // a row past the end contributes nothing
+      const float live = row0 + u * stride < R ? 1.f : 0.f;
+      csw.x += v.x; csw.y += v.y; csw.z += v.z; csw.w += v.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[j].x = fmaf(v.x, t[u][j], acc[j].x); acc[j].y = fmaf(v.y, t[u][j], acc[j].y);
+        acc[j].z = fmaf(v.z, t[u][j], acc[j].z); acc[j].w = fmaf(v.w, t[u][j], acc[j].w);
+        cst[j] += live * t[u][j];
+      }
+    }
+  }
+  // the GROUPS row groups of the workgroup meet in LDS, one thin column at a time, and are added in group order
+  const int64_t PQ = (int64_t)g.M * g.N;
+  float* part = g.partial + (int64_t)blockIdx.x * PQ;
+  float* pcs = g.partial_colsum ? g.partial_colsum + (int64_t)blockIdx.x * g.M : nullptr;
+  for (int j = 0; j <= T; ++j) {
+    float4 mine = csw;                                      // (the pass after the last thin column: the wide column sums)
+    if (j < T) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mine = j == q ? acc[q] : mine;
+    }
+    __syncthreads();
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x < W) {
+      const int c = threadIdx.x;
+      float sgm = 0.f;
+      for (int gi = 0; gi < GROUPS; ++gi) sgm += reinterpret_cast<const float*>(&red[gi * LPR + (c >> 2)])[c & 3];
+      if (j < T) part[WIDE_IS_A ? (int64_t)c * T + j : (int64_t)j * W + c] = sgm;
+      else if (WIDE_IS_A && pcs) pcs[c] = sgm;
+    }
+  }
+  if (!WIDE_IS_A && pcs) {                                  // thin column sums: every lane of a group holds the same ones
+    __syncthreads();
+    float* rf = reinterpret_cast<float*>(red);
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rf[grp * 8 + j] = cst[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+      float sgm = 0.f;
+      for (int gi = 0; gi < GROUPS; ++gi) sgm += rf[gi * 8 + threadIdx.x];
+      pcs[threadIdx.x] = sgm;
+    }
+  }
+}
+
+// The thin kernels take plain layers only (no mask, gate only on a wide dY, no dropout, no accumulation); everything
+// else, and the NO_THIN option, stays on the tiled kernels.
+template <bool A_KC, bool B_KC>
+static int thin_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
+  if (mbvae_opt(MBVAE_OPT_NO_THIN)) return MBVAE_EUNSUPPORTED;
+  if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.a_mask_mode != MBVAE_MASK_NONE || g.c_mask_mode != MBVAE_MASK_NONE || g.drop_p > 0.f ||
+      g.accumulate || g.addend || g.c_gate)
+    return MBVAE_EUNSUPPORTED;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const int blocks = 8 * ts_num_cus();
+  if (A_KC) {                                              // forward / input gradient: rows = g.M
+    if (g.M < 32768 || g.a_gate) return MBVAE_EUNSUPPORTED;
+    if (g.K <= 8 && g.N % 4 == 0 && pow2(g.N / 4) && g.N <= 1024 && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+        (B_KC || ((g.ldb & 3) == 0 && ((uintptr_t)g.B & 15) == 0)) && (!g.bias || ((uintptr_t)g.bias & 15) == 0)) {
+#define THIN_IN(kt) case kt: hipLaunchKernelGGL((thin_in_kernel<kt, B_KC>), dim3(blocks), dim3(256), 0, stream, g); break;
+      switch (g.K) { THIN_IN(1) THIN_IN(2) THIN_IN(3) THIN_IN(4) THIN_IN(5) THIN_IN(6) THIN_IN(7) THIN_IN(8) }
+#undef THIN_IN
+      return mbvae_launch_status();
+    }
+    if (B_KC && g.N <= 8 && g.K % 4 == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) {
+      if (g.K == 64) hipLaunchKernelGGL(thin_out_kernel<16>, dim3(blocks), dim3(256), 0, stream, g);
+      else if (g.K == 128) hipLaunchKernelGGL(thin_out_kernel<32>, dim3(blocks), dim3(256), 0, stream, g);
+      else if (g.K == 256) hipLaunchKernelGGL(thin_out_kernel<64>, dim3(blocks), dim3(256), 0, stream, g);
+      else return MBVAE_EUNSUPPORTED;
+      return mbvae_launch_status();
+    }
+    return MBVAE_EUNSUPPORTED;
+  }
+  if (B_KC) return MBVAE_EUNSUPPORTED;
+  // weight gradient: A = dY [R, P], B = X [R, Q], C = dW [P, Q] (contiguous), R = g.K rows
+  const int P = g.M, Q = g.N;
+  if (g.K < 32768 || g.ldc != Q || workspace == nullptr) return MBVAE_EUNSUPPORTED;
+  const bool wide_a = Q <= 8 && (P == 64 || P == 128 || P == 256);
+  const bool wide_b = P <= 8 && (Q == 64 || Q == 128 || Q == 256) && !g.a_gate;
+  if (!wide_a && !wide_b) return MBVAE_EUNSUPPORTED;
+  const float* wide = wide_a ? g.A : g.B;
+  const int64_t ldw = wide_a ? g.lda : g.ldb;
+  if ((ldw & 3) || ((uintptr_t)wide & 15) || (wide_a && g.a_gate && ((uintptr_t)g.a_gate & 15))) return MBVAE_EUNSUPPORTED;
+  const int wblocks = 2 * ts_num_cus();       // (1024-thread workgroups, one per CU, measured 15 % slower)
+  const int64_t need = (int64_t)wblocks * ((int64_t)P * Q + P) * 4;
+  if (ws_bytes < need) return MBVAE_EUNSUPPORTED;
+  g.partial = (float*)workspace;
+  g.partial_colsum = g.colsum ? g.partial + (int64_t)wblocks * P * Q : nullptr;
+  const int Wd = wide_a ? P : Q;
+  // rows per trip: four where the wide operand is the only wide stream, two next to a gate operand (same bytes in flight)
+#define THIN_WG(lpr)                                                                                                  \
+  do {                                                                                                                 \
+    if (wide_a && g.a_gate) hipLaunchKernelGGL((thin_wgrad_kernel<lpr, true, 2>), dim3(wblocks), dim3(256), 0, stream, g);  \
+    else if (wide_a) hipLaunchKernelGGL((thin_wgrad_kernel<lpr, true, 4>), dim3(wblocks), dim3(256), 0, stream, g);   \
+    else hipLaunchKernelGGL((thin_wgrad_kernel<lpr, false, 4>), dim3(wblocks), dim3(256), 0, stream, g);              \
+  } while (0)
+  if (Wd == 64) THIN_WG(16); else if (Wd == 128) THIN_WG(32); else THIN_WG(64);
+#undef THIN_WG
+  const int64_t total = (int64_t)P * Q + P;
+  hipLaunchKernelGGL(tswgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, g, wblocks);
+  return mbvae_launch_status();
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
   if (!g.A || !g.B || !g.C) return MBVAE_EINVAL;
   const bool bf16 = g.a_bf16 || g.b_bf16 || g.c_bf16;
+  {
+    const int st = thin_try<A_KC, B_KC>(g, workspace, ws_bytes, stream);
+    if (st != MBVAE_EUNSUPPORTED) return st;
+  }
   if (A_KC) {
     const int st = tsgemm_try<B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;

@@ -59,6 +59,11 @@ def ragged_mask(bs, n, gen):
     # few output tiles, long reduction: one 32x32 tile per workgroup, the reduction split over its four waves
     (256, 4170, 512, 0, "none"), (256, 1024, 2048, 1, "none"), (256, 256, 1024, 0, "none"), (32, 2048, 512, 1, "none"),
     (256, 2048, 100, 1, "none"), (200, 1000, 72, 0, "none"), (256, 512, 128, 1, "none"), (48, 136, 1024, 0, "none"),
+    # thin layers over the pair rows (the 5 bond classes at either end of the edge MLPs): streaming kernels, no tiles;
+    # odd row counts exercise the clamped second row of a trip
+    (16 * 64 * 64, 5, 128, 1, "none"), (16 * 64 * 64, 128, 5, 0, "none"), (9 * 64 * 64 + 3, 5, 128, 0, "none"),
+    (9 * 64 * 64 + 3, 128, 5, 1, "none"), (40000, 8, 64, 1, "none"), (40000, 64, 8, 0, "none"), (33000, 3, 256, 0, "none"),
+    (33000, 256, 1, 0, "none"),
 ])
 def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     g = torch.Generator().manual_seed(M + K + N)
