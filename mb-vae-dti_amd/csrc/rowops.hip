@@ -453,7 +453,43 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   const int64_t total = (int64_t)gridDim.y * L * d4;    // gridDim.y = bs
   const int b = blockIdx.y;
   const float invL = 1.f / L;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)L * d4; e += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t gstride = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gstride % d4 == 0) {
+    // The lane keeps its four channels for the whole walk over l: the statistics and their gradients are loaded once
+    // and folded into dx = base + slope * x (+ dmin / dmax at the arg rows); four rows per trip, loads first.
+    const int c = (int)(e0 % d4) * 4, lstep = (int)(gstride / d4);
+    const float* st = stats + (int64_t)b * 4 * D; const float* ds = dstats + (int64_t)b * 4 * D;
+    const float4 mean = ld4(st + c), sd = ld4(st + 3 * D + c);
+    const float4 dmean = ld4(ds + c), dmin = ld4(ds + D + c), dmax = ld4(ds + 2 * D + c), dsd = ld4(ds + 3 * D + c);
+    const int4 amn = *reinterpret_cast<const int4*>(arg + ((int64_t)b * 2 + 0) * D + c);
+    const int4 amx = *reinterpret_cast<const int4*>(arg + ((int64_t)b * 2 + 1) * D + c);
+    const float k = 1.f / (L - 1.f);
+    for (int l0 = (int)(e0 / d4); l0 < L; l0 += 4 * lstep) {
+      float4 v[4], p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + u * lstep, L - 1);
+        const int64_t off = ((int64_t)b * L + l) * D + c;
+        v[u] = ld4(x + off);
+        p[u] = accumulate ? ld4(dx + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = l0 + u * lstep;
+        if (l < L) {
+          float4 o;      // same expression as the general loop below (bit-identical results)
+          o.x = dmean.x * invL + (sd.x > 0.f ? dsd.x * (v[u].x - mean.x) * k / sd.x : 0.f) + (l == amn.x ? dmin.x : 0.f) + (l == amx.x ? dmax.x : 0.f);
+          o.y = dmean.y * invL + (sd.y > 0.f ? dsd.y * (v[u].y - mean.y) * k / sd.y : 0.f) + (l == amn.y ? dmin.y : 0.f) + (l == amx.y ? dmax.y : 0.f);
+          o.z = dmean.z * invL + (sd.z > 0.f ? dsd.z * (v[u].z - mean.z) * k / sd.z : 0.f) + (l == amn.z ? dmin.z : 0.f) + (l == amx.z ? dmax.z : 0.f);
+          o.w = dmean.w * invL + (sd.w > 0.f ? dsd.w * (v[u].w - mean.w) * k / sd.w : 0.f) + (l == amn.w ? dmin.w : 0.f) + (l == amx.w ? dmax.w : 0.f);
+          if (accumulate) { o.x += p[u].x; o.y += p[u].y; o.z += p[u].z; o.w += p[u].w; }
+          st4(dx + ((int64_t)b * L + l) * D + c, o);
+        }
+      }
+    }
+    return;
+  }
+  for (int64_t e = e0; e < (int64_t)L * d4; e += gstride) {
     const int l = (int)(e / d4), c = (int)(e % d4) * 4;
     const int64_t off = ((int64_t)b * L + l) * D + c;
     const float4 v = ld4(x + off);
