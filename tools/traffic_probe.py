@@ -125,6 +125,33 @@ with torch.enable_grad():
     y = ops.ln_residual(x, r, g, b, 1e-5, 0.1, 7)
     mark("mbvae_ln_residual_bwd:E")
     y.backward(dy)
+    # a 64-wide Linear with the residual LayerNorm in its epilogue, and the LayerNorm backward from the stored sum
+    # (entry points called directly: one kernel per segment)
+    from mbvae_amd import _lib as _ll
+    stl = torch.cuda.current_stream().cuda_stream
+    wsl = ops.workspace(x.device)
+    mark("setup")
+    for K in (256, 128):
+        xin = torch.randn(M, K, device=dev); wl = torch.randn(64, K, device=dev) / K ** 0.5; bl = torch.zeros(64, device=dev)
+        yl, zl = torch.empty(M, 64, device=dev), torch.empty(M, 64, device=dev)
+        args_l = (xin.data_ptr(), K, wl.data_ptr(), bl.data_ptr(), x.data_ptr(), g.data_ptr(), b.data_ptr(), yl.data_ptr(), zl.data_ptr(),
+                  M, K, 64, mask.view(torch.uint8).data_ptr(), 2, n, 1e-5, 0.1, 7, stl)
+        _ll.call("mbvae_linear_ln_fwd", *args_l)
+        torch.cuda.synchronize()
+        mark(f"mbvae_linear_ln_fwd:{M}x{K}x64")
+        _ll.call("mbvae_linear_ln_fwd", *args_l)
+        mark("setup")
+        del xin
+    dxl, drl = torch.empty(M, 64, device=dev), torch.empty(M, 64, device=dev)
+    dgl, dbl = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    args_s = (zl.data_ptr(), g.data_ptr(), dy.data_ptr(), dxl.data_ptr(), drl.data_ptr(), dgl.data_ptr(), dbl.data_ptr(), M, 64, 1e-5, 0.1, 7,
+              wsl.data_ptr(), wsl.numel(), stl)
+    _ll.call("mbvae_ln_sum_bwd", *args_s)
+    torch.cuda.synchronize()
+    mark("mbvae_ln_sum_bwd:E")
+    _ll.call("mbvae_ln_sum_bwd", *args_s)
+    mark("setup")
+    del yl, zl, dxl, drl
     mark("mbvae_pool_stats_fwd:E")
     s = ops.pool_stats(x)
     # the backward entry point on its own, accumulating into an existing gradient as it does in the denoiser step
