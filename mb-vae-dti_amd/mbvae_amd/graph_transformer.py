@@ -85,7 +85,7 @@ class NodeEdgeBlock(nn.Module):
         return ops.linear(x, w, b, **kw)
 
     def forward(self, X, E, y, node_mask, return_edge_alias=False, edge_norm=None, tile_map=None, order=None, pack=None,
-                edge_norm_train=None):
+                edge_norm_train=None, side=None):
         """(newX, newE, new_y) as in the reference; with return_edge_alias also an alias of E that the caller should
         use for the residual branch, so that all gradients of E meet inside one autograd node (ops.edge_input).
         pack (ops.NodePack, inference only): X and newX are packed node rows [rows, dx] instead of [bs, n, dx]."""
@@ -102,6 +102,28 @@ class NodeEdgeBlock(nn.Module):
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head,
                                                  order=order if edge_norm is not None else None, pack=pack)
+        def node_and_global_updates():
+            if pack is not None:
+                film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
+            elif torch.is_grad_enabled():
+                film = (ops.film(yx_add, yx_mul, wV) if dx % 4 == 0 and not ops.option_set("NO_FILM")
+                        else yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV)
+            else:                                  # same arithmetic in two element-wise kernels instead of three
+                film = torch.addcmul(yx_add.unsqueeze(1), yx_mul.unsqueeze(1) + 1, wV)
+            nX = _lin(self.x_out, film, **node)
+            x_stats = _lin(self.x_y.lin, ops.pool_stats_nodes(X, pack)) if pack is not None else self.x_y(X)
+            ny = yy + x_stats + _lin(self.e_y.lin, e_stats)
+            return nX, _lin(self.y_out[2], _lin(self.y_out[0], ny, act=1))
+
+        if side is not None:
+            # second stream, forked BEFORE the long e_out kernel is issued: these small kernels only need the attention
+            # block's outputs; the caller joins the streams at the end of the layer.  Tensors of this stream that the other
+            # one reads are marked for the allocator.
+            side.wait_stream(torch.cuda.current_stream())
+            for t in (X, yp, wV, e_stats):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                newX, new_y = node_and_global_updates()
         if edge_norm is not None:       # inference: e_out, the residual add and the layer's first edge LayerNorm in one pass
             ln, eps = edge_norm
             newE = ops.edge_out_ln_inference(P, self.e_out.weight, self.e_out.bias, E, node_mask, n, ln.weight, ln.bias, eps,
@@ -119,17 +141,8 @@ class NodeEdgeBlock(nn.Module):
             else:
                 newE = _lin(self.e_out, P, **edge)
                 self.__dict__["_edge_normed"] = False
-        if pack is not None:
-            film = torch.addcmul(yx_add[pack.graph], yx_mul[pack.graph] + 1, wV)
-        elif torch.is_grad_enabled():
-            film = (ops.film(yx_add, yx_mul, wV) if dx % 4 == 0 and not ops.option_set("NO_FILM")
-                    else yx_add.unsqueeze(1) + (yx_mul.unsqueeze(1) + 1) * wV)
-        else:                                  # same arithmetic in two element-wise kernels instead of three
-            film = torch.addcmul(yx_add.unsqueeze(1), yx_mul.unsqueeze(1) + 1, wV)
-        newX = _lin(self.x_out, film, **node)
-        x_stats = _lin(self.x_y.lin, ops.pool_stats_nodes(X, pack)) if pack is not None else self.x_y(X)
-        new_y = yy + x_stats + _lin(self.e_y.lin, e_stats)
-        new_y = _lin(self.y_out[2], _lin(self.y_out[0], new_y, act=1))
+        if side is None:
+            newX, new_y = node_and_global_updates()
         return (newX, newE, new_y, E_alias) if return_edge_alias else (newX, newE, new_y)
 
 
@@ -161,36 +174,53 @@ class XEyTransformerLayer(nn.Module):
         # dropout seeds in the order the three first norms use them (X, y, E), drawn before the attention block because
         # the edge norm may run inside it
         sX1, sy1, sE1 = seeds.next(), seeds.next(), seeds.next()
+        # training: the node / global remainder of the layer on a second stream next to the long edge-tensor kernels
+        side = ops.side_stream(X.device) if (torch.is_grad_enabled() and not inference and X.is_cuda and pack is None) else None
+        if side is not None:
+            y.record_stream(side)
         newX, newE, new_y, E = self.self_attn(X, E, y, node_mask, return_edge_alias=True,
                                               edge_norm=(self.normE1, self.eps) if inference else None,
                                               tile_map=tile_map if inference else None,
                                               order=order if inference else None,
                                               pack=pack if inference else None,
-                                              edge_norm_train=None if inference else (self.normE1, self.eps, p, sE1))
+                                              edge_norm_train=None if inference else (self.normE1, self.eps, p, sE1),
+                                              side=side)
 
         def norm(ln, x, r, seed=None):
             return ops.ln_residual(x, r, ln.weight, ln.bias, self.eps, p, seeds.next() if seed is None else seed)
 
-        X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
         # (inference, or training with the fused epilogue: newE already is normE1(E + dropout(e_out(.))))
-        E = newE if (inference or self.self_attn.__dict__.get("_edge_normed")) else norm(self.normE1, E, newE, sE1)
+        def edge_norm1():
+            return newE if (inference or self.self_attn.__dict__.get("_edge_normed")) else norm(self.normE1, E, newE, sE1)
 
-        def ff_block(ln, l1, l2, x):
+        def ff_block(ln, l1, l2, x, s_ffn, s_norm):
             """norm(x + dropout(l2(dropout(relu(l1(x)))))); the residual branch uses l1's alias of x so that both
             gradients of x meet inside l1's input-gradient product.  Where the second Linear takes the LayerNorm into
             its epilogue (the edge tensor) ffn returns the normalised result itself."""
-            s_ffn, s_norm = seeds.next(), seeds.next()
             out, x = ops.ffn(x, l1.weight, l1.bias, l2.weight, l2.bias, drop_p=p, seed=s_ffn,
                              ln=(ln.weight, ln.bias, self.eps, p, s_norm))
             return out if x is None else norm(ln, x, out, s_norm)
 
-        X = ff_block(self.normX2, self.linX1, self.linX2, X)
+        sXf, sEf, syf = [(seeds.next(), seeds.next()) for _ in range(3)]      # seeds in the order X, E, y use them
+        if side is not None:
+            with torch.cuda.stream(side):
+                X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
+                X = ff_block(self.normX2, self.linX1, self.linX2, X, *sXf)
+                y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y, *syf)
+            E = ff_block(self.normE2, self.linE1, self.linE2, edge_norm1(), *sEf)
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            X.record_stream(main); y.record_stream(main)
+            return X, E, y
+        X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
+        E = edge_norm1()
+        X = ff_block(self.normX2, self.linX1, self.linX2, X, *sXf)
         if inference:                                     # the edge feed-forward block in one pass
             E = ops.ffn_ln_inference(E, self.linE1.weight, self.linE1.bias, self.linE2.weight, self.linE2.bias,
                                      self.normE2.weight, self.normE2.bias, self.eps, tile_map=tile_map, order=order)
         else:
-            E = ff_block(self.normE2, self.linE1, self.linE2, E)
-        y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y)
+            E = ff_block(self.normE2, self.linE1, self.linE2, E, *sEf)
+        y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y, *syf)
         return X, E, y
 
 

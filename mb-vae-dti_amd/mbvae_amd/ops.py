@@ -39,8 +39,8 @@ def _ptr(t):
 
 
 def workspace(device, nbytes=160 << 20):
-    """Per-device scratch buffer shared by all kernels (they are serialised on the stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffer per (device, stream), shared by all kernels issued on that stream (which serialises them)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -54,11 +54,36 @@ _queue_cache = {}
 def _work_counter(device):
     """One int32 per device for kernels that hand out their tasks through a counter (they run serialised on the stream
     and zero it themselves)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     q = _queue_cache.get(key)
     if q is None:
         q = _queue_cache[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return q
+
+
+_side_streams = {}
+_SIDE_STREAM = [os.environ.get("MBVAE_SIDE_STREAM", "0") not in ("", "0")]      # (the test suite runs both ways)
+
+
+def set_side_stream(on):
+    """Training: run the node / global-feature remainder of a transformer layer (small, latency-bound kernels) on a
+    second HIP stream next to the layer's long edge-tensor kernels.  Off by default; not under gradient-sync hooks or
+    HIP graph capture."""
+    _SIDE_STREAM[0] = bool(on)
+    if on and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        # parameter gradients produced on the second stream are accumulated on the parameters' own stream: intended
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
+def side_stream(device):
+    """The device's second stream when set_side_stream(True) and nothing is being captured, else None."""
+    if not _SIDE_STREAM[0] or torch.cuda.is_current_stream_capturing():
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def option_set(name):

@@ -3,6 +3,8 @@
 FullDTIModel._common_step / training_step for the decoder branch (mb_vae_dti/training/modules/full.py:816-952,
 :1174-1211) with the optimiser of AbstractDTIModel.configure_optimizers (training/modules/utils.py:109-116).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -40,7 +42,14 @@ def synthetic_graphs(bs, n, device, generator, sizes=None):
 
 class DenoiserTrainStep:
     def __init__(self, cfg=CFG3, T=500, lr=5e-4, weight_decay=1e-4, lambdas=(1.0, 5.0), device="cuda", distributed=False,
-                 seed=0):
+                 seed=0, side_stream=None):
+        # the node / global remainder of every layer on a second stream (not next to gradient-sync hooks, which launch
+        # their collectives from inside the backward pass); MBVAE_SIDE_STREAM=0/1 overrides
+        if side_stream is None:
+            side_stream = not distributed
+        if os.environ.get("MBVAE_SIDE_STREAM") is not None:
+            side_stream = os.environ["MBVAE_SIDE_STREAM"] not in ("", "0")
+        ops.set_side_stream(side_stream and not distributed)
         torch.manual_seed(seed)                      # identical initial weights on every rank
         self.device = torch.device(device)
         self.model = GraphTransformer(**cfg).to(self.device).train()
