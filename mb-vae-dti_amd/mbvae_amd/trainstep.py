@@ -42,7 +42,7 @@ def synthetic_graphs(bs, n, device, generator, sizes=None):
 
 class DenoiserTrainStep:
     def __init__(self, cfg=CFG3, T=500, lr=5e-4, weight_decay=1e-4, lambdas=(1.0, 5.0), device="cuda", distributed=False,
-                 seed=0, side_stream=None):
+                 seed=0, side_stream=None, overlap_optimizer=False):
         # the node / global remainder of every layer on a second stream (not next to gradient-sync hooks, which launch
         # their collectives from inside the backward pass); MBVAE_SIDE_STREAM=0/1 overrides
         if side_stream is None:
@@ -68,9 +68,21 @@ class DenoiserTrainStep:
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=True,
                                      fused=True)
         self.last = {}
+        self._params = [p for p in self.model.parameters() if p.requires_grad]
+        self._opt_pending = None
+        # overlap_optimizer (needs the second stream): the weight update is left running on the second stream when step()
+        # returns and the NEXT step's denoiser call waits for it; anyone else who reads the weights calls
+        # wait_optimizer() first.  Off: step() returns with the update ordered into the caller's stream.
+        self.overlap_optimizer = overlap_optimizer
         # identical weights everywhere, but every rank draws its own timesteps, noise and dropout seeds
         rank = torch.distributed.get_rank() if (distributed and torch.distributed.is_initialized()) else 0
         torch.manual_seed(seed + 1 + rank)
+
+    def wait_optimizer(self):
+        """Orders a weight update that was left running on the second stream into the current stream."""
+        if self._opt_pending is not None:
+            torch.cuda.current_stream().wait_stream(self._opt_pending)
+            self._opt_pending = None
 
     def step(self, X0, E0, mask, cond):
         bs, n, cx = X0.shape
@@ -86,6 +98,7 @@ class DenoiserTrainStep:
         Xm, ym = self.mol_feats(X_t, E_t, truncate_weight=True)
         X_in = torch.cat((X_t, Xg, Xm), 2)
         y_in = torch.cat((cond, yg, ym, t), 1)
+        self.wait_optimizer()                       # the previous step's weight update may still run on the second stream
         pred = self.model(X_in, E_t, y_in, mask)
         lX, sX = ops.masked_ce(pred.X, X0)
         lE, sE = ops.masked_ce(pred.E, E0)
@@ -93,7 +106,22 @@ class DenoiserTrainStep:
         loss.backward()
         if self.sync is not None:
             self.sync.finish()
-        self.opt.step()
+        side = ops.side_stream(dev) if self.sync is None else None
+        if side is None:
+            self.opt.step()
+        else:
+            # The optimiser's sweep over the weights (memory bound) on the second stream: the next step's noising and
+            # graph features (latency bound, no weights involved) start next to it; the denoiser waits for it below.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            for p in self._params:
+                if p.grad is not None:
+                    p.grad.record_stream(side)       # (freed right after this call; the allocator must wait for the sweep)
+            with torch.cuda.stream(side):
+                self.opt.step()
+            self._opt_pending = side
+            if not self.overlap_optimizer:
+                self.wait_optimizer()
         if self.sync is not None:
             self.sync.zero_grad()
         else:

@@ -1107,6 +1107,34 @@ def test_train_step_gradients_are_bitwise_reproducible():
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), f"gradient of {k} differs between two identical runs"
 
+def test_train_step_with_overlapped_optimizer_gives_identical_weights():
+    """DenoiserTrainStep with the second stream and the weight update left running under the next step's noising /
+    features: after four steps the losses and every weight equal those of the plain one-stream trainer bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mbvae_amd import ops as O
+    from mbvae_amd.trainstep import CFG3, DenoiserTrainStep, synthetic_graphs
+    cfg = dict(CFG3); cfg["n_layers"] = 2
+    g = torch.Generator().manual_seed(9)
+    X0, E0, mask = synthetic_graphs(16, 64, "cuda", g)
+    cond = torch.randn(16, 1024, generator=g).cuda()
+    was = O._SIDE_STREAM[0]
+    try:
+        runs = []
+        for side in (False, True):
+            tr = DenoiserTrainStep(cfg, device="cuda", seed=1, side_stream=side, overlap_optimizer=side)
+            torch.manual_seed(77)
+            losses = [tr.step(X0, E0, mask, cond) for _ in range(4)]
+            tr.wait_optimizer()
+            torch.cuda.synchronize()
+            runs.append((torch.stack(losses).clone(), {k: v.detach().clone() for k, v in tr.model.named_parameters()}))
+        assert torch.equal(runs[0][0], runs[1][0])
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], runs[1][1][k]), f"weight {k} differs"
+    finally:
+        O.set_side_stream(was)
+
+
 def test_second_stream_for_node_and_global_updates_is_bitwise_identical():
     """ops.set_side_stream(True): the node / global-feature remainder of every layer runs on a second HIP stream next to
     the long edge-tensor kernels.  Same kernels, same sums: outputs, loss and every parameter gradient must equal the
