@@ -301,14 +301,30 @@ class GraphTransformer(nn.Module):
             hv = mlp(self.mlp_in_E, Eflat[pack.pair_rows], True)
             hE = hv.new_zeros((Eflat.shape[0], hv.shape[-1])).index_copy_(0, pack.pair_rows, hv)
             hE = ops.sym_mask(hE.reshape(*E.shape[:-1], -1), node_mask)
-        else:
+        # training with a second stream: the node / global input and output MLPs (small) next to the edge ones (long)
+        side = ops.side_stream(X.device) if (torch.is_grad_enabled() and self.training and X.is_cuda and pack is None) else None
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
+            for t in (X, y, xm):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
+                hy = mlp(self.mlp_in_y, y, True)
             hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
-        if pack is not None:
+            main.wait_stream(side)
+            hX.record_stream(main); hy.record_stream(main)
+        elif pack is None:
+            hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
+        if side is not None:
+            pass
+        elif pack is not None:
             Xflat = X.reshape(-1, X.shape[-1])
             hX = mlp(self.mlp_in_X, Xflat[pack.rows], True, mask=pack.keep, mask_mode=ops.MASK_NODE, n_nodes=pack.keep.shape[1])
         else:
             hX = mlp(self.mlp_in_X, X, True, mask=node_mask, mask_mode=ops.MASK_NODE, n_nodes=n)
-        hy = mlp(self.mlp_in_y, y, True)
+        if side is None:
+            hy = mlp(self.mlp_in_y, y, True)
         for layer in self.tf_layers:
             hX, hE, hy = layer(hX, hE, hy, node_mask, seeds, tile_map=tile_map, order=order, pack=pack)
         if pack is not None:                         # the edge output MLP on the valid pairs only, likewise
@@ -321,6 +337,14 @@ class GraphTransformer(nn.Module):
             valid = pack.rows[:pack.n_valid]
             oXp = mlp(self.mlp_out_X, hX, False)[:pack.n_valid] + Xflat[valid, :self.out_dim_X]
             oX = oXp.new_zeros((Xflat.shape[0], self.out_dim_X)).index_copy_(0, valid, oXp).reshape(*X.shape[:-1], -1)
+        elif side is not None:                       # (hX, hy were produced on the second stream: no wait needed)
+            with torch.cuda.stream(side):
+                oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
+                oy = mlp(self.mlp_out_y, hy, False) + y[..., :self.out_dim_y]
+            oE = ops.sym_mask(mlp(self.mlp_out_E, hE, False), node_mask, skip=E, zero_diag=True)
+            main.wait_stream(side)
+            oX.record_stream(main); oy.record_stream(main)
+            return PlaceHolder(X=oX, E=oE, y=oy)
         else:
             oX = (mlp(self.mlp_out_X, hX, False) + X[..., :self.out_dim_X]) * xm
         if pack is None:
