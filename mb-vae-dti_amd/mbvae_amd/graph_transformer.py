@@ -95,9 +95,23 @@ class NodeEdgeBlock(nn.Module):
         if pack is not None:            # every packed row is a valid node except the one padding row
             node = dict(mask=pack.keep, mask_mode=ops.MASK_NODE, n_nodes=pack.keep.shape[1])
         edge = dict(mask=node_mask, mask_mode=ops.MASK_EDGE, n_nodes=n)
-        QKV = self._fused("qkv", X, (self.q, self.k, self.v), **node)            # [bs,n,3dx]
+        if side is not None:
+            # the two small projections that open the block also run on the second stream: in the forward pass they are
+            # issued behind the previous layer's node / global work (done long before the main stream gets here), in
+            # the backward pass their gradient kernels run next to the edge projection's
+            main = torch.cuda.current_stream()
+            if not (getattr(X, "_mbvae_stream", None) is side and getattr(y, "_mbvae_stream", None) is side):
+                side.wait_stream(main)               # X, y were not produced on the second stream
+                X.record_stream(side); y.record_stream(side)
+            with torch.cuda.stream(side):
+                QKV = self._fused("qkv", X, (self.q, self.k, self.v), **node)
+                yp = self._fused("y5", y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
+            main.wait_stream(side)
+            QKV.record_stream(main); yp.record_stream(main)
+        else:
+            QKV = self._fused("qkv", X, (self.q, self.k, self.v), **node)            # [bs,n,3dx]
+            yp = self._fused("y5", y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         w12, b12 = self._stacked("e12", (self.e_mul, self.e_add))
-        yp = self._fused("y5", y, (self.y_e_add, self.y_e_mul, self.y_x_add, self.y_x_mul, self.y_y))
         ye_add, ye_mul, yx_add, yx_mul, yy = yp.split((dx, dx, dx, dx, self.dy), dim=-1)
         # e_mul|e_add projection + attention (+ Etoy statistics and the residual alias of E) as one node
         P, wV, e_stats, E_alias = ops.edge_block(E, w12, b12, QKV, ye_add, ye_mul, node_mask, self.n_head,
@@ -211,6 +225,7 @@ class XEyTransformerLayer(nn.Module):
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             X.record_stream(main); y.record_stream(main)
+            X._mbvae_stream = y._mbvae_stream = side      # (the next layer's opening projections need not wait for `main`)
             return X, E, y
         X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
         E = edge_norm1()
@@ -314,6 +329,7 @@ class GraphTransformer(nn.Module):
             hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
             main.wait_stream(side)
             hX.record_stream(main); hy.record_stream(main)
+            hX._mbvae_stream = hy._mbvae_stream = side
         elif pack is None:
             hE = ops.sym_mask(mlp(self.mlp_in_E, E, True), node_mask)
         if side is not None:

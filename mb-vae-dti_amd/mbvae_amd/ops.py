@@ -65,6 +65,10 @@ _side_streams = {}
 _SIDE_STREAM = [os.environ.get("MBVAE_SIDE_STREAM", "0") not in ("", "0")]      # (the test suite runs both ways)
 
 
+if _SIDE_STREAM[0] and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # (intended, see set_side_stream)
+
+
 def set_side_stream(on):
     """Training: run the node / global-feature remainder of a transformer layer (small, latency-bound kernels) on a
     second HIP stream next to the layer's long edge-tensor kernels.  Off by default; not under gradient-sync hooks or
