@@ -70,6 +70,11 @@ int mbvae_linear_ln_fwd(const float* x, int64_t ldx, const float* w, const float
                         const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
                         const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
                         mbvae_stream_t stream);
+/* The same with x stored as bf16: e_out on the attention output P of the bf16 storage mode (see the *_bf16 entry points). */
+int mbvae_linear_ln_fwd_bf16(const uint16_t* x, int64_t ldx, const float* w, const float* bias, const float* resid,
+                             const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                             const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                             mbvae_stream_t stream);
 /* dx[M,K] = out_gate[M,K] > 0 ? (rowmask(dy)[M,N] @ w[N,K]) * out_gate_scale : 0.  out_gate is this layer's INPUT when that
  * input came out of ReLU (+ dropout) - linE2 / linX2 / lin_y2 of the feed-forward blocks, graph_transformer.py:139-146 -:
  * the gate of the layer below is applied where the gradient is produced, and that layer's gradient calls take gate = NULL. */

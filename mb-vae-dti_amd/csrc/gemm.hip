@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512) void tsgemm_kernel(GemmArgs g) {
 template <int TN, bool B_KC, bool GATE, int WAVES, bool ADD = false, int SPLIT = 0, bool ABF = false, bool CBF = false, bool CGATE = false,
           bool LNE = false>
 __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
-  static_assert(!LNE || (TN == 2 && ADD && !CBF && !CGATE && !ABF), "the LayerNorm epilogue: 64-wide fp32 rows with a residual operand");
+  static_assert(!LNE || (TN == 2 && ADD && !CBF && !CGATE), "the LayerNorm epilogue: 64-wide fp32 output rows with a residual operand");
   static_assert(!(ABF && (GATE || SPLIT == 0)), "a bf16 A operand runs on the bf16 pipeline and has no gate");
   static_assert(!(ADD && CGATE) && !(CGATE && CBF), "an output gate comes without an addend and with fp32 output");
   constexpr int NP = ABF ? 4 : 8;                  // 16-byte words of A per lane and 64-wide reduction group
@@ -2249,32 +2249,50 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
 // epilogue, so the Linear's output never travels through memory; z is kept for mbvae_ln_sum_bwd.  The dropout mask is
 // the one mbvae_ln_residual_fwd would draw for (seed, element index).  MBVAE_EUNSUPPORTED for shapes the wave-autonomous
 // tall-skinny kernel does not take (run the Linear and mbvae_ln_residual_fwd separately then).
-int mbvae_linear_ln_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* resid,
-                        const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
-                        const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
-                        hipStream_t stream) {
+static int linear_ln_fwd_impl(const void* x, int x_bf16, int64_t ldx, const float* w, const float* bias, const float* resid,
+                              const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                              const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                              hipStream_t stream) {
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !w || !resid || !gamma || !beta || !y || !z || M <= 0) return MBVAE_EINVAL;
   if (mask_mode != MBVAE_MASK_NONE && (!mask || n_nodes <= 0)) return MBVAE_EINVAL;
   if (mbvae_opt(MBVAE_OPT_NO_TSGEMM) || mbvae_opt(MBVAE_OPT_NO_TSGEMM2) || mbvae_opt(MBVAE_OPT_NO_LN_EPILOGUE)) return MBVAE_EUNSUPPORTED;
   if (N != 64 || K % 64 || K <= 0 || K > 512 || M % 32 || M < 8192 || M * 64 >= 0x3fffffff) return MBVAE_EUNSUPPORTED;
-  if ((((uintptr_t)x | (uintptr_t)resid | (uintptr_t)y | (uintptr_t)z) & 15) || (ldx & 3)) return MBVAE_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)resid | (uintptr_t)y | (uintptr_t)z) & 15) || (ldx & (x_bf16 ? 7 : 3))) return MBVAE_EUNSUPPORTED;
   GemmArgs g = {};
-  g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = 64; g.K = (int)K;
-  g.lda = ldx; g.ldb = K; g.ldc = 64;
+  g.A = reinterpret_cast<const float*>(x); g.B = w; g.C = y; g.M = (int)M; g.N = 64; g.K = (int)K;
+  g.lda = ldx; g.ldb = K; g.ldc = 64; g.a_bf16 = x_bf16;
   g.a_gate_scale = 1.f; g.mask = mask; g.c_mask_mode = mask_mode; g.n_nodes = n_nodes;
   g.bias = bias; g.drop_p = drop_p; g.seed = seed;
   g.addend = resid; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_z = z; g.ln_eps = eps;
   const size_t smem3 = 2 * 3 * (size_t)64 * (K + 8), smemf = sizeof(float) * (size_t)K * 65;
-  const bool split1 = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && smem3 <= MBVAE_LDS_LIMIT;
+  // (a bf16 operand always runs on the bf16 pipeline)
+  const bool split1 = (x_bf16 || !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA)) && smem3 <= MBVAE_LDS_LIMIT;
+  if (x_bf16 && !split1) return MBVAE_EUNSUPPORTED;
   const size_t smem = split1 ? smem3 : smemf;
   if (smem > MBVAE_LDS_LIMIT) return MBVAE_EUNSUPPORTED;
+  auto kb = tsgemm2_kernel<2, true, false, 8, true, 1, true, false, false, true>;
   auto ks = tsgemm2_kernel<2, true, false, 8, true, 1, false, false, false, true>;
   auto kf = tsgemm2_kernel<2, true, false, 8, true, 0, false, false, false, true>;
-  if (!(split1 ? MBVAE_ALLOW_BIG_LDS(ks) : MBVAE_ALLOW_BIG_LDS(kf))) return MBVAE_ELAUNCH;
+  if (!(x_bf16 ? MBVAE_ALLOW_BIG_LDS(kb) : split1 ? MBVAE_ALLOW_BIG_LDS(ks) : MBVAE_ALLOW_BIG_LDS(kf))) return MBVAE_ELAUNCH;
   const int grid = std::min(std::max((int)(M / 256), 1), ts_num_cus());
-  hipLaunchKernelGGL(split1 ? ks : kf, dim3(grid), dim3(512), smem, stream, g);
+  hipLaunchKernelGGL(x_bf16 ? kb : split1 ? ks : kf, dim3(grid), dim3(512), smem, stream, g);
   return mbvae_launch_status();
+}
+
+int mbvae_linear_ln_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* resid,
+                        const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                        const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                        hipStream_t stream) {
+  return linear_ln_fwd_impl(x, 0, ldx, w, bias, resid, gamma, beta, y, z, M, K, N, mask, mask_mode, n_nodes, eps, drop_p, seed, stream);
+}
+
+// The same with x stored as bf16 (the attention output P of the bf16 storage mode feeding e_out).
+int mbvae_linear_ln_fwd_bf16(const uint16_t* x, int64_t ldx, const float* w, const float* bias, const float* resid,
+                             const float* gamma, const float* beta, float* y, float* z, int64_t M, int64_t K, int64_t N,
+                             const uint8_t* mask, int mask_mode, int n_nodes, float eps, float drop_p, uint64_t seed,
+                             hipStream_t stream) {
+  return linear_ln_fwd_impl(x, 1, ldx, w, bias, resid, gamma, beta, y, z, M, K, N, mask, mask_mode, n_nodes, eps, drop_p, seed, stream);
 }
 
 // dx[M,K] = pro(dy)[M,N] @ w[N,K] + addend[M,K] (addend laid out like dx).  Only shapes served by the persistent

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],
     "mbvae_ln_residual_fwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P],
     "mbvae_linear_ln_fwd": [_P, _L] + [_P] * 7 + [_L, _L, _L, _P, _I, _I, _F, _F, _U, _P],
+    "mbvae_linear_ln_fwd_bf16": [_P, _L] + [_P] * 7 + [_L, _L, _L, _P, _I, _I, _F, _F, _U, _P],
     "mbvae_ln_sum_bwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P, _L, _P],
     "mbvae_ln_residual_bwd_workspace": [_L],
     "mbvae_ln_residual_bwd": [_P] * 10 + [_L, _L, _F, _U, _P, _L, _P],

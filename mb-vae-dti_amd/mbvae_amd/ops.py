@@ -564,13 +564,14 @@ class _LinearLn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, resid, gamma, beta, mask, mask_mode, n_nodes, eps, drop_p, seed, in_gate_scale):
-        x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
+        bf16_in = x.dtype == torch.bfloat16          # bf16 storage mode: the attention output P feeding e_out
+        x2 = x.contiguous().reshape(-1, x.shape[-1]) if bf16_in else _f32c(x, "x").reshape(-1, x.shape[-1])
         w, resid, gamma, beta = _f32c(w, "weight"), _f32c(resid, "resid"), _f32c(gamma), _f32c(beta)
         M, K = x2.shape
         N = w.shape[0]
         m8 = _mask_u8(mask)
         y, z = torch.empty_like(resid), torch.empty_like(resid)
-        ok = _lib.call("mbvae_linear_ln_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), resid.data_ptr(), gamma.data_ptr(),
+        ok = _lib.call("mbvae_linear_ln_fwd_bf16" if bf16_in else "mbvae_linear_ln_fwd", x2.data_ptr(), K, w.data_ptr(), _ptr(b), resid.data_ptr(), gamma.data_ptr(),
                        beta.data_ptr(), y.data_ptr(), z.data_ptr(), M, K, N, _ptr(m8), mask_mode, n_nodes, float(eps),
                        float(drop_p), int(seed), _stream(), tag=(M, K, N), allow_unsupported=True)
         if not ok:
@@ -608,7 +609,7 @@ def linear_ln_supported(x, weight, resid):
     """Shapes mbvae_linear_ln_fwd takes: a 64-wide fp32 Linear over >= 8192 rows (the edge tensor's e_out and linE2)."""
     M = x.numel() // x.shape[-1]
     K = x.shape[-1]
-    return (x.is_cuda and x.dtype == torch.float32 and weight.shape[0] == 64 and resid.shape[-1] == 64 and K % 64 == 0
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.shape[0] == 64 and resid.shape[-1] == 64 and K % 64 == 0
             and K <= 384 and M >= 8192 and M % 32 == 0 and M * 64 < 0x3fffffff
             and not (option_set("NO_LN_EPILOGUE") or option_set("NO_TSGEMM") or option_set("NO_TSGEMM2")))
 

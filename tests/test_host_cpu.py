@@ -1,6 +1,7 @@
 """CPU-only checks of the host logic: C-ABI exports, dense-batch convention, schedule mirror, DDP gradient sync."""
 import ctypes
 import os
+import sys
 import re
 import socket
 
@@ -98,6 +99,15 @@ def test_to_dense_convention():
     assert torch.equal(E, E.transpose(1, 2))
 
 
+def _leave_group():
+    """End of a spawned gloo worker.  Both ranks leave together, and the interpreter is left without running the C++
+    static destructors: with them, a worker now and then dies in std::terminate ('terminate called without an active
+    exception', a background thread of the process group still joinable) AFTER all its checks have passed."""
+    dist.barrier()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -156,7 +166,7 @@ def _ddp_worker(rank, world, port, out):
     result["one_rank_only"] = torch.cat([p.grad.reshape(-1).clone() for p in net["unused_head"].parameters()])
     if rank == 0:
         torch.save(result, out)
-    dist.destroy_process_group()
+    _leave_group()
 
 
 def test_bucketed_grad_sync_gloo_world2(tmp_path):
@@ -230,7 +240,7 @@ def _sampling_worker(rank, world, port, out):
     assert (res is None) == (rank != 0)
     if rank == 0:
         torch.save([[list(pair) for pair in grp] for grp in res], out)
-    dist.destroy_process_group()
+    _leave_group()
 
 
 def test_sharded_sampling_gloo_world2(tmp_path):
