@@ -140,9 +140,7 @@ def main():
     from mbvae_amd import _lib
     from mbvae_amd.trainstep import CFG3, DenoiserTrainStep, synthetic_graphs
 
-    # one GPU: second stream for the small node / global kernels and for the weight update (it runs under the next
-    # step's noising and graph features); with gradient sync (N > 1) both stay on the main stream
-    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0, overlap_optimizer=world == 1)
+    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0)
     g = torch.Generator().manual_seed(1000 + rank)          # a different data shard per rank
     bs, n = args.batch, args.nodes
     X0, E0, mask = synthetic_graphs(bs, n, dev, g)
