@@ -5,7 +5,7 @@ import torch
 from mbvae_amd.trainstep import CFG3, DenoiserTrainStep, synthetic_graphs
 g = torch.Generator().manual_seed(1000)
 sizes = torch.randint(30, 65, (256,), generator=g); sizes[0] = 64
-X0, E0, mask = synthetic_graphs(256, 64, "cuda", g, sizes=sizes)
+X0, E0, mask = synthetic_graphs(256, 64, "cuda", g, sizes=None if os.environ.get("CHECK_FULL") == "1" else sizes)
 cond = torch.randn(256, 1024, generator=g).cuda()
 runs = []
 OVERLAP = os.environ.get("CHECK_OVERLAP", "1") == "1"
