@@ -1107,78 +1107,6 @@ def test_train_step_gradients_are_bitwise_reproducible():
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), f"gradient of {k} differs between two identical runs"
 
-def test_train_step_with_overlapped_optimizer_gives_identical_weights():
-    """DenoiserTrainStep with the second stream and the weight update left running under the next step's noising /
-    features: after four steps the losses and every weight equal those of the plain one-stream trainer bit for bit."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    from mbvae_amd import ops as O
-    from mbvae_amd.trainstep import CFG3, DenoiserTrainStep, synthetic_graphs
-    cfg = dict(CFG3); cfg["n_layers"] = 2
-    g = torch.Generator().manual_seed(9)
-    X0, E0, mask = synthetic_graphs(16, 64, "cuda", g)
-    cond = torch.randn(16, 1024, generator=g).cuda()
-    was = O._SIDE_STREAM[0]
-    try:
-        runs = []
-        for side in (False, True):
-            tr = DenoiserTrainStep(cfg, device="cuda", seed=1, side_stream=side, overlap_optimizer=side)
-            torch.manual_seed(77)
-            losses = [tr.step(X0, E0, mask, cond) for _ in range(4)]
-            tr.wait_optimizer()
-            torch.cuda.synchronize()
-            runs.append((torch.stack(losses).clone(), {k: v.detach().clone() for k, v in tr.model.named_parameters()}))
-        assert torch.equal(runs[0][0], runs[1][0])
-        for k in runs[0][1]:
-            assert torch.equal(runs[0][1][k], runs[1][1][k]), f"weight {k} differs"
-    finally:
-        O.set_side_stream(was)
-
-
-def test_second_stream_for_node_and_global_updates_is_bitwise_identical():
-    """ops.set_side_stream(True): the node / global-feature remainder of every layer runs on a second HIP stream next to
-    the long edge-tensor kernels.  Same kernels, same sums: outputs, loss and every parameter gradient must equal the
-    one-stream run bit for bit, over several steps in a row (a missed dependency or an early buffer reuse would show)."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    from mbvae_amd import ops as O
-    from mbvae_amd.graph_transformer import GraphTransformer
-    from mbvae_amd.trainstep import CFG3, synthetic_graphs
-    cfg = dict(CFG3); cfg["n_layers"] = 3
-    torch.manual_seed(4)
-    net = GraphTransformer(**cfg).cuda().train()
-    g = torch.Generator().manual_seed(6)
-    bs, n = 32, 64
-    sizes = torch.randint(20, n + 1, (bs,), generator=g); sizes[0] = n
-    X0, E0, mask = synthetic_graphs(bs, n, "cuda", g, sizes=sizes)
-    Xin = torch.cat((X0, torch.randn(bs, n, 8, generator=g).cuda() * mask.unsqueeze(-1)), 2)
-    yin = torch.randn(bs, 1037, generator=g).cuda()
-
-    def run(side, seed):
-        O.set_side_stream(side)
-        try:
-            net.zero_grad(set_to_none=True)
-            torch.manual_seed(seed)                      # same dropout seeds
-            out = net(Xin, E0, yin, mask)
-            lX, _ = O.masked_ce(out.X, X0); lE, _ = O.masked_ce(out.E, E0)
-            loss = lX + 5 * lE + out.y.pow(2).mean()
-            loss.backward()
-            torch.cuda.synchronize()
-            return loss.detach().clone(), out.X.detach().clone(), out.y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
-        finally:
-            O.set_side_stream(False)
-
-    was = O._SIDE_STREAM[0]
-    try:
-        for seed in (21, 22, 23):
-            a, b = run(False, seed), run(True, seed)
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-            for k in a[3]:
-                assert torch.equal(a[3][k], b[3][k]), f"gradient of {k} differs with the second stream (seed {seed})"
-    finally:
-        O.set_side_stream(was)
-
-
 def test_grad_sync_rccl_world1_matches_plain_step():
     """The bucketed gradient all-reduce over RCCL (world size 1 on the single test GPU) leaves the train step unchanged:
     flat-bucket gradient views, async all-reduce from hooks, divide, zero_grad re-arming."""
