@@ -95,7 +95,7 @@ def launch_workers(n):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes (this same script, one per GPU,
     rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, wait for them, and pass on the worst
     exit status.  Rank 0 prints the JSON line on the inherited stdout."""
-    have = torch.cuda.device_count()            # (counting devices does not initialise the GPU runtime)
+    have = torch.cuda.device_count()            # (the children are started before this process makes any other GPU call)
     if have < n:
         print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible", file=sys.stderr)
         return 2
@@ -155,8 +155,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.PROFILE = {}
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()                     # the timed region carries no instrumentation
     for _ in range(args.steps):
         loss = trainer.step(X0, E0, mask, cond)
     torch.cuda.synchronize()
@@ -164,11 +163,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    profile, _lib.PROFILE = _lib.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # Per-kernel durations for the roofline object come from a SEPARATE, untimed pass over the same steps: every C-ABI
+    # call bracketed by HIP events on the stream it is launched on (two event records per call would otherwise sit
+    # inside the timed region).
+    profile = {}
+    if rank == 0:
+        _lib.PROFILE = profile
+        try:
+            for _ in range(args.steps):
+                trainer.step(X0, E0, mask, cond)
+            torch.cuda.synchronize()
+        finally:
+            _lib.PROFILE = None
+    elif world > 1:                              # the other ranks run the same steps (the gradient all-reduce is collective)
+        for _ in range(args.steps):
+            trainer.step(X0, E0, mask, cond)
+        torch.cuda.synchronize()
     # second, separately labelled measurement (N = 1 only): the opt-in bf16 STORAGE mode of the edge block's large
     # activations (fp32 weights and arithmetic; parity bound 2e-2 instead of 1e-5).  Never the headline `value`.
     bf16_line = None
