@@ -140,7 +140,9 @@ def main():
     from mbvae_amd import _lib
     from mbvae_amd.trainstep import CFG3, DenoiserTrainStep, synthetic_graphs
 
-    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0)
+    # second stream for the node / global-feature kernels (bit-identical to one stream, tests/test_gpu_two_streams.py);
+    # on one GPU the weight update additionally runs on it under the next step's noising and graph features
+    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0, side_stream=True, overlap_optimizer=world == 1)
     g = torch.Generator().manual_seed(1000 + rank)          # a different data shard per rank
     bs, n = args.batch, args.nodes
     X0, E0, mask = synthetic_graphs(bs, n, dev, g)
@@ -158,6 +160,7 @@ def main():
     t0 = time.perf_counter()                     # the timed region carries no instrumentation
     for _ in range(args.steps):
         loss = trainer.step(X0, E0, mask, cond)
+    trainer.wait_optimizer()                     # the last weight update is part of the last step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -11,11 +11,18 @@ Semantics are those of a single process that averages the ranks' gradients:
 * A parameter that received no gradient on ANY rank in a step ends the step with `.grad = None`, exactly as it would
   without this class: the optimiser skips it (no weight decay, no moment updates).  A parameter used on some ranks
   only gets the mean over all ranks, zeros counting for the others.  The ranks agree on the used set with one tiny
-  MAX all-reduce per step; with static_graph=True that happens in the first step only and the set is reused, which
+  MIN all-reduce per step (a parameter is unused everywhere iff the minimum of the "unused here" flags is still 1); with static_graph=True that happens in the first step only and the set is reused, which
   also lets a bucket holding never-used parameters launch from the hooks instead of waiting for finish().
+* Gradients may be produced on more than one GPU stream (ops.set_side_stream: node / global-feature kernels on a
+  second stream).  A collective only orders itself behind the stream it is launched from, so every hook notes the
+  stream its gradient was accumulated on and a bucket's launch first makes the launching stream wait for all of them.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_TRACE = os.environ.get("MBVAE_DDP_TRACE") is not None      # prints every bucket launch and every wait
 
 
 class BucketedGradSync:
@@ -64,11 +71,15 @@ class BucketedGradSync:
         self._ready = [0] * len(self.buckets)
         self._next = 0               # buckets [0, _next) have been launched
         self._seen = [False] * len(self.params)
+        self._streams = [{} for _ in self.buckets]      # per bucket: GPU streams its gradients were accumulated on
 
     def _hook(self, p):
         self._seen[self._index[p]] = True
         b = self._bucket_of[p]
         self._ready[b] += 1
+        if p.is_cuda:                # (the hook runs on the stream of the parameter's gradient accumulation)
+            st = torch.cuda.current_stream(p.device)
+            self._streams[b][st.cuda_stream] = st
         self._launch_ready()
 
     def _launch_ready(self):
@@ -78,9 +89,28 @@ class BucketedGradSync:
             self._next += 1
 
     def _launch(self, b):
+        flat = self.buckets[b][0]
+        if flat.is_cuda and self._streams[b]:
+            # every kernel that wrote into this bucket has been issued by now (the last hook fired after it): order the
+            # launching stream behind the other streams that took part, then the collective behind the launching stream
+            cur = torch.cuda.current_stream(flat.device)
+            for handle, st in self._streams[b].items():
+                if handle != cur.cuda_stream:
+                    cur.wait_stream(st)
+        if _TRACE:
+            import threading
+            print(f"[ddp rank {dist.get_rank() if dist.is_initialized() else 0}] launch bucket {b} ({flat.numel()} values) from "
+                  f"{threading.current_thread().name}, ready {self._ready} expected {self._expected}", flush=True)
+        work = self._collective(flat)
+        if work is not None:
+            self._pending.append((work, flat))
+
+    def _collective(self, flat):
+        """Sum of `flat` over the ranks, asynchronous, ordered behind the current stream; None when there is nothing to wait
+        for (one rank)."""
         if self.world > 1:
-            flat = self.buckets[b][0]
-            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
 
     def finish(self):
         """Call after backward(): launches what the hooks could not (buckets holding a parameter without gradient),
@@ -99,7 +129,9 @@ class BucketedGradSync:
                 self._unused = unused
                 drop = set(unused)
                 self._expected = [sum(1 for p in plist if self._index[p] not in drop) for _, plist in self.buckets]
-        for work, flat in self._pending:
+        for k, (work, flat) in enumerate(self._pending):
+            if _TRACE:
+                print(f"[ddp rank {dist.get_rank()}] waiting for collective {k} of {len(self._pending)}", flush=True)
             work.wait()
             flat.div_(self.world)
         self._pending.clear()

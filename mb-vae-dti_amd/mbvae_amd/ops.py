@@ -71,8 +71,9 @@ if _SIDE_STREAM[0] and hasattr(torch.autograd.graph, "set_warn_on_accumulate_gra
 
 def set_side_stream(on):
     """Training: run the node / global-feature remainder of a transformer layer (small, latency-bound kernels) on a
-    second HIP stream next to the layer's long edge-tensor kernels.  Off by default; not under gradient-sync hooks or
-    HIP graph capture."""
+    second HIP stream next to the layer's long edge-tensor kernels.  Same kernels, same sums: results are bit-identical
+    to one stream.  Not used while a HIP graph is being captured; gradient-sync hooks order their collectives behind
+    both streams (ddp.BucketedGradSync)."""
     _SIDE_STREAM[0] = bool(on)
     if on and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         # parameter gradients produced on the second stream are accumulated on the parameters' own stream: intended

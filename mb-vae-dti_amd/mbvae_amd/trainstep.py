@@ -43,16 +43,13 @@ def synthetic_graphs(bs, n, device, generator, sizes=None):
 class DenoiserTrainStep:
     def __init__(self, cfg=CFG3, T=500, lr=5e-4, weight_decay=1e-4, lambdas=(1.0, 5.0), device="cuda", distributed=False,
                  seed=0, side_stream=None, overlap_optimizer=False):
-        # side_stream (experimental, OFF by default): the node / global remainder of every layer on a second stream (never
-        # next to gradient-sync hooks, which launch their collectives from inside the backward pass).  One step is
-        # bit-identical to the one-stream run at the sizes the tests use, but 256-graph trajectories differ in the last
-        # bits from the third step on and from run to run - an ordering hazard that has not been found yet - so nothing
-        # that is reported uses it.  MBVAE_SIDE_STREAM=0/1 overrides.
+        # side_stream: the node / global-feature remainder of every layer on a second HIP stream next to the long edge-tensor
+        # kernels (ops.set_side_stream; bit-identical to one stream, tests/test_gpu_two_streams.py).  None = on for a GPU
+        # model unless MBVAE_SIDE_STREAM=0; an explicit True / False is never overridden by the environment.  With
+        # gradient-sync hooks the collectives order themselves behind both streams (ddp.BucketedGradSync).
         if side_stream is None:
-            side_stream = False
-        if os.environ.get("MBVAE_SIDE_STREAM") is not None:
-            side_stream = os.environ["MBVAE_SIDE_STREAM"] not in ("", "0")
-        ops.set_side_stream(side_stream and not distributed)
+            side_stream = torch.device(device).type == "cuda" and os.environ.get("MBVAE_SIDE_STREAM", "1") not in ("", "0")
+        ops.set_side_stream(bool(side_stream))
         torch.manual_seed(seed)                      # identical initial weights on every rank
         self.device = torch.device(device)
         self.model = GraphTransformer(**cfg).to(self.device).train()
