@@ -91,6 +91,29 @@ def linear_flops(name, tag):
     return (4.0 if name == "mbvae_linear_bwd_both" else 2.0) * M * K * N
 
 
+def extra_objects():
+    """cfg5 / cfg2 / cfg4 of the benchmark list on this GPU: reverse-diffusion sampling (one rank's share of 10 000 molecules:
+    1 250, sizes ~ N(28, 7^2), 20 reverse steps), the multi-branch encoder train step (as one captured HIP graph) and the
+    joint FullDTIModel training step, 256 pairs each.  Child processes (tools/bench_sampling.py, tools/bench_configs.py);
+    a failing child leaves an error string in its place."""
+    def child(script, *argv):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", script), *argv]
+        try:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            return [{"error": "timed out"}]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode != 0 or not lines:
+            return [{"error": f"exit status {res.returncode}: " + res.stderr.strip()[-300:]}]
+        return [json.loads(l) for l in lines]
+
+    out = {"sampling": child("bench_sampling.py", "--chunk", "1250", "--steps", "20")[0]}
+    enc = child("bench_configs.py", "--which", "encoders", "--graph", "--steps", "10")
+    out["cfg2_encoder_step"] = enc[0]
+    out["cfg4_joint_step"] = child("bench_configs.py", "--which", "joint", "--steps", "5")[0]
+    return out
+
+
 def launch_workers(n):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes (this same script, one per GPU,
     rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, wait for them, and pass on the worst
@@ -122,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the second, labelled bf16-storage measurement")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the additional labelled objects (sampling, encoder step, joint step; N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -173,19 +198,19 @@ def main():
     # Per-kernel durations for the roofline object come from a SEPARATE, untimed pass over the same steps: every C-ABI
     # call bracketed by HIP events on the stream it is launched on (two event records per call would otherwise sit
     # inside the timed region).
+    # That pass runs on ONE stream, so that a kernel's duration is its own and not that of whatever shared the GPU with it.
     profile = {}
-    if rank == 0:
-        _lib.PROFILE = profile
-        try:
-            for _ in range(args.steps):
-                trainer.step(X0, E0, mask, cond)
-            torch.cuda.synchronize()
-        finally:
-            _lib.PROFILE = None
-    elif world > 1:                              # the other ranks run the same steps (the gradient all-reduce is collective)
-        for _ in range(args.steps):
+    trainer.wait_optimizer()
+    ops.set_side_stream(False)
+    try:
+        if rank == 0:
+            _lib.PROFILE = profile
+        for _ in range(args.steps):              # (every rank runs the same steps: the gradient all-reduce is collective)
             trainer.step(X0, E0, mask, cond)
         torch.cuda.synchronize()
+    finally:
+        _lib.PROFILE = None
+        ops.set_side_stream(True)
     # second, separately labelled measurement (N = 1 only): the opt-in bf16 STORAGE mode of the edge block's large
     # activations (fp32 weights and arithmetic; parity bound 2e-2 instead of 1e-5).  Never the headline `value`.
     bf16_line = None
@@ -197,6 +222,7 @@ def main():
             tb = time.perf_counter()
             for _ in range(args.steps):
                 trainer.step(X0, E0, mask, cond)
+            trainer.wait_optimizer()
             torch.cuda.synchronize()
             eb = time.perf_counter() - tb
         finally:
@@ -310,6 +336,13 @@ def main():
             r = rows.get(nm)
             if r and r["ms"] > 0:
                 roofline[nm[6:] + "_GBps"] = round(ea_bytes[nm] / (r["ms"] / r["calls"] * 1e-3) / 1e9, 1)
+        # the loss kernels (node + edge logits of one step): forward reads logits and one-hot targets, backward also writes
+        # the logit gradient; 5 classes, fp32
+        ce_rows = bs * n + bs * n * n
+        for nm, per_row in (("mbvae_masked_ce_fwd", 2 * 5 * 4), ("mbvae_masked_ce_bwd", 3 * 5 * 4)):
+            r = rows.get(nm)
+            if r and r["ms"] > 0:
+                roofline[nm[6:] + "_GBps"] = round(ce_rows * per_row * args.steps / (r["ms"] * 1e-3) / 1e9, 1)
         # whole-step figures: ~15.0 GFLOP and, with only layer inputs/outputs touching memory, ~61.5 MB per graph
         per_gpu_rate = bs * args.steps / elapsed
         roofline["whole_step_TFLOPs"] = round(per_gpu_rate * 15.0e9 / 1e12, 2)
@@ -327,6 +360,12 @@ def main():
         }
         if bf16_line is not None:
             out["bf16_storage_mode"] = bf16_line
+        if world == 1 and not args.no_extra:
+            # further labelled measurements of the same library (never `value`): each in a fresh child process after this
+            # one has released its GPU memory
+            del trainer, X0, E0, mask, cond
+            torch.cuda.empty_cache()
+            out.update(extra_objects())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CFG3, n)
         print(json.dumps(out), flush=True)

@@ -6,9 +6,13 @@
  *   - nothing is allocated, freed or synchronised: outputs and workspaces are caller-owned, work is
  *     enqueued on `stream` and the call returns immediately;
  *   - return value: 0 ok, -1 invalid argument, -2 unsupported shape, -3 launch failure; no exceptions;
- *   - re-entrant and thread-safe.  The library keeps no mutable state per call; process-wide it holds (a) tables
- *     filled once and read-only afterwards (compute-unit count and kernel LDS limits per device) and (b) the tuning
- *     switches of mbvae_set_option below (relaxed atomics).
+ *   - threads: entry points may be called from several host threads at once as long as concurrent calls do not share
+ *     a workspace, an output or a work counter (calls on ONE stream are serialised by the stream; the Python host keeps
+ *     one workspace per stream).  Not safe to overlap on one GPU, and said so where they are declared: the entry points
+ *     that hand out tasks through a caller-owned device counter (work_counter arguments) when they share that counter,
+ *     and mbvae_masked_ce_fwd_static, whose partial sums live in one static device array per GPU.  Process-wide the
+ *     library holds (a) tables filled once and read-only afterwards (compute-unit count and kernel LDS limits per
+ *     device) and (b) the tuning switches of mbvae_set_option below (relaxed atomics).
  * The reference has no native interface; each entry point replaces the sequence of PyTorch ops cited
  * next to it (paths relative to the reference repository root).
  */
@@ -28,16 +32,29 @@ typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
 
 /* ---- tuning switches ------------------------------------------------------------------------------------
  * No counterpart in the reference.  Process-wide switches that choose between equivalent HIP routes (kernel A/B
- * timing, parity tests of the fallback kernels; never a CPU path).  Names: "NO_TSGEMM", "NO_TSGEMM2", "TSGEMM_N64",
- * "NO_TSWGRAD", "NO_TSWGRAD2", "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED", "NO_EA_PREFETCH" (0 / 1),
- * "EA_KEYS" (8, else 16 keys per wave in the attention backward) and "GEMM_TILE" (-1 automatic, 0 = 64x64,
- * 1 = 128x64, 2 = 128x128).  Each starts from the environment variable
- * MBVAE_<NAME>, read once.  mbvae_set_option: 0, or -1 for an unknown name.  mbvae_get_option: the value (-1 for an
- * unknown name).  A change takes effect at the next entry-point call. */
+ * timing, parity tests of the fallback kernels; never a CPU path).  Each starts from the environment variable
+ * MBVAE_<NAME>, read once.  The 24 names (0 / 1 unless a range is given):
+ *   kernel families   NO_TSGEMM, NO_TSGEMM2 (tall-skinny products over the pair rows), TSGEMM_N64, NO_TSWGRAD, NO_TSWGRAD2
+ *                     (their weight gradients), NO_SMALLM (few-tile products of the global-feature path), NO_COLGROUPS
+ *                     (node-path column groups), NO_THIN (the 5-wide ends of the edge MLPs), GEMM_TILE (-1 automatic,
+ *                     0 = 64x64, 1 = 128x64, 2 = 128x128 tiles of the generic kernel)
+ *   arithmetic        NO_SPLIT_MFMA (edge-path products on the native fp32 matrix instructions instead of six bf16 ones)
+ *   attention block   NO_EDGE_FUSED, NO_EDGE_TRAIN_FUSED, NO_E12_RECOMPUTE (store e_mul|e_add instead of recomputing it in
+ *                     the backward), NO_EF_COOP / NO_EFB_COOP (operand tile split per wave instead of once per
+ *                     workgroup, forward / backward), EF_STAGGER (0..3: how the waves of a workgroup are phased),
+ *                     EFB_SYNC (rendezvous period of the recomputing backward in query rows, power of two; 0 = 8),
+ *                     EA_KEYS (8, else 16 keys per wave in the storing attention backward), NO_EA_PREFETCH
+ *   fusions           NO_EDGE_FFN (inference feed-forward block), NO_LN_EPILOGUE (Linear + LayerNorm), NO_BWD_BOTH (both
+ *                     gradients of e_mul|e_add from one pass), NO_FFN_HANDOVER and NO_FILM (read by the host side)
+ * mbvae_set_option: 0, or -1 for an unknown name.  mbvae_get_option: the value (-1 for an unknown name; GEMM_TILE's
+ * "automatic" is -1 as well).  A change takes effect at the next entry-point call. */
 int mbvae_set_option(const char* name, int value);
 int mbvae_get_option(const char* name);
 
-/* ---- Linear layers on the matrix cores (fp32 MFMA) -------------------------------------------------
+/* ---- Linear layers on the matrix cores ------------------------------------------------------------------
+ * fp32 in, fp32 out, fp32 accumulation.  Products over the pair rows ([bs*n*n, d] shapes) run on the bf16 matrix
+ * instructions with every fp32 operand cut exactly into three bf16 words (six products per fp32 product, error as the
+ * native fp32 instruction's); all other shapes run on the native fp32 matrix instruction.
  * Replaces nn.Linear forward/backward plus the `* x_mask`, `* e_mask1 * e_mask2`, ReLU and Dropout that
  * surround it in mb_vae_dti/training/models/graph_transformer.py:201-202,217-221,233,240,257 (NodeEdgeBlock),
  * :134-144 (feed-forward blocks), :283-308,321-335 (in/out MLPs) and the encoder / head MLPs of

@@ -568,8 +568,8 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
   float keepf[2];                                   // row-mask flag of this lane's row in the staged tile
   float bjr[2][TN];                                 // bias of the task's columns: loaded with the operands, a load in the
                                                     // epilogue would stall the stores behind a full memory latency
-  const float* biasp = g.bias ? g.bias : g.A;       // any readable address when there is no bias (value ignored)
-  const float has_bias = g.bias ? 1.f : 0.f;
+  const float* biasp = g.bias ? g.bias : g.A;       // any readable address when there is no bias (the value is never used:
+                                                    // selected away, not multiplied by zero - it may be non-finite)
   f32x16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
     }                                                                                                  \
     if ((q) == 0) {                                    /* first task: accumulators start at its bias */ \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-        _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[j][v] = bjr[S][j] * has_bias;               \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) acc[j][v] = g.bias ? bjr[S][j] : 0.f;           \
     }                                                                                                  \
   }
 #define TS2_MMA(q, S)                                                                                 \
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64 * WAVES) void tsgemm2_kernel(GemmArgs g) {
       const unsigned kh = (unsigned)(kb >> (4 * h));   /* bit i: row 4h+i of the tile survives */      \
       const unsigned sbase = (((unsigned)tile * 32u) * ldc + cb * (32 * TN)) * CS;   /* wave-uniform byte offset */ \
       float bn[TN];                                                                                    \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = bjr[1 - S][j] * has_bias;                 \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bn[j] = g.bias ? bjr[1 - S][j] : 0.f;             \
       if (LNE) {                                       /* residual + dropout + LayerNorm over the task's 32 whole rows */ \
         const unsigned off0 = ((unsigned)tile * 32u + 4u * h) * ldc + r;                               \
         float zz[2][16], mu[16], rs[16];                                                               \
@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(512) void proj_bwd_kernel(ProjBwdArgs g) {
     asm volatile("" : : : "memory");                                                                   \
     PB_WGRAD(ra[S], S)                                                                                 \
     PB_DGRAD(dl)                                                                                       \
-    asm volatile("s_barrier" : : : "memory");          /* the previous group's partial tiles have been read; every wave is done with this group's X planes */ \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");   /* the previous group's partial tiles have been read; every wave is done with this group's X planes (its LDS reads have RETURNED: the products that consume them may be scheduled past this point) */ \
     _Pragma("unroll") for (int et = 0; et < 4; ++et)                                                   \
       _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                    \
         part[wave * 1024 + (4 * q4 + v) * 64 + ((et ^ q4) << 4) + m16] = dxa[et][v];                   \

@@ -574,13 +574,13 @@ __global__ __launch_bounds__(256) void ln_res_fwd_generic_kernel(const float* __
   }
 }
 
-// Generic backward; dgamma/dbeta accumulate with float atomics into zeroed buffers (odd widths only occur on
-// small [batch, D] tensors).
+// Generic backward (any width): one wave per row writes dx / dr; dgamma and dbeta come from a second kernel in which a
+// thread owns a column and walks a block of rows in order, followed by the fixed-order sum of the row blocks' partials
+// (colsum_partials_kernel) - no atomics, bitwise reproducible like the vectorised kernels.
 __global__ __launch_bounds__(256) void ln_res_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                  const float* __restrict__ rstd_in, const float* __restrict__ dy,
                                                                  float* __restrict__ dx, float* __restrict__ dr,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  int64_t rows, int D, float drop_p, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
@@ -596,14 +596,33 @@ __global__ __launch_bounds__(256) void ln_res_bwd_generic_kernel(const float* __
     const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
     for (int c = lane; c < D; c += 64) {
       const int64_t off = row * D + c;
-      const float d = dy[off], xh = xhat(c);
-      const float dz = rstd * (d * gamma[c] - m1 - xh * m2);
+      const float dz = rstd * (dy[off] * gamma[c] - m1 - xhat(c) * m2);
       dx[off] = dz;
       if (dr) dr[off] = dz * mbvae_drop_scale(drop_p, seed, off);
-      atomicAdd(&dgamma[c], d * xh);
-      atomicAdd(&dbeta[c], d);
     }
   }
+}
+
+// part[blockIdx.y][0][c] = sum over the block's rows of dy * xhat, part[blockIdx.y][1][c] = sum of dy (rows in order)
+__global__ __launch_bounds__(256) void ln_res_bwd_generic_colsum_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                        const float* __restrict__ dy, float* __restrict__ part,
+                                                                        int64_t rows, int D, int64_t rows_per_block, float drop_p,
+                                                                        uint64_t seed) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float sg = 0.f, sb = 0.f;
+  for (int64_t row = r0; row < r1; ++row) {
+    const int64_t off = row * D + c;
+    float z = x[off];
+    if (r) z += r[off] * mbvae_drop_scale(drop_p, seed, off);
+    const float d = dy[off];
+    sg += d * ((z - mean_in[row]) * rstd_in[row]);
+    sb += d;
+  }
+  part[((int64_t)blockIdx.y * 2 + 0) * D + c] = sg;
+  part[((int64_t)blockIdx.y * 2 + 1) * D + c] = sb;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,11 +691,16 @@ int mbvae_ln_residual_bwd(const float* x, const float* r, const float* gamma, co
                        dr, dgamma, dbeta, (float*)workspace, floats, rows, 0.f, drop_p, seed, stream);
   if (st != MBVAE_EUNSUPPORTED) return st;
   if (D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, stream) != hipSuccess) return MBVAE_ELAUNCH;
-  if (hipMemsetAsync(dbeta, 0, sizeof(float) * D, stream) != hipSuccess) return MBVAE_ELAUNCH;
   const int64_t blocks = std::min<int64_t>((rows + 3) / 4, 1024);
   hipLaunchKernelGGL(ln_res_bwd_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, r, gamma, mean, rstd, dy,
-                     dx, dr, dgamma, dbeta, rows, (int)D, drop_p, seed);
+                     dx, dr, rows, (int)D, drop_p, seed);
+  int64_t row_blocks = std::min<int64_t>(std::min<int64_t>(256, rows), floats / (2 * D));
+  const int64_t rpb = (rows + row_blocks - 1) / row_blocks;
+  row_blocks = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(ln_res_bwd_generic_colsum_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)row_blocks), dim3(256), 0, stream, x, r,
+                     mean, rstd, dy, (float*)workspace, rows, (int)D, rpb, drop_p, seed);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)((2 * D + 31) / 32)), dim3(256), 0, stream, (const float*)workspace, dgamma, dbeta,
+                     (int)row_blocks, (int)(2 * D), (int)D);
   return mbvae_launch_status();
 }
 

@@ -260,3 +260,19 @@ def test_sharded_sampling_gloo_world2(tmp_path):
         assert len(g_grp) == len(w_grp) == 3
         for (ga, gb), (wa, wb) in zip(g_grp, w_grp):
             assert torch.equal(ga, wa) and torch.equal(gb, wb)
+
+
+def test_header_lists_every_tuning_switch():
+    """include/mbvae_hip.h names every option of the library's table (csrc/common.h), and no others."""
+    common = open(os.path.join(ROOT, "mb-vae-dti_amd", "csrc", "common.h")).read()
+    table = common[common.index("static const char* const names[MBVAE_OPT_COUNT]"):]
+    names = re.findall(r'"([A-Z0-9_]+)"', table[:table.index("};")])
+    enum = common[common.index("enum MbvaeOption"):common.index("MBVAE_OPT_COUNT")]
+    assert len(names) == len(re.findall(r"MBVAE_OPT_[A-Z0-9_]+", enum)) >= 24
+    header = open(os.path.join(ROOT, "include", "mbvae_hip.h")).read()
+    doc = header[header.index("---- tuning switches"):header.index("int mbvae_set_option")]
+    for n in names:
+        assert re.search(r"\b" + n + r"\b", doc), f"option {n} is not documented in include/mbvae_hip.h"
+    mentioned = set(re.findall(r"\b((?:NO_|EA_|EF_|EFB_|TSGEMM_|GEMM_)[A-Z0-9_]+)\b", doc))
+    assert mentioned <= set(names), mentioned - set(names)
+    assert f"The {len(names)} names" in doc

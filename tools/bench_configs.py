@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--kernel-table", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="joint: keep the decoder's node / global kernels on the main stream")
     ap.add_argument("--graph", action="store_true",
                     help="encoders only: capture the whole step (forward, backward, AdamW) in one HIP graph and time replays")
     args = ap.parse_args()
@@ -127,8 +128,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    from mbvae_amd import _lib
+    from mbvae_amd import _lib, ops
     from mbvae_amd.ddp import BucketedGradSync
+    ops.set_side_stream(not args.one_stream)     # (never active while a HIP graph is being captured)
 
     model = build_model(dev)
     g = torch.Generator().manual_seed(1000 + rank)
