@@ -205,3 +205,56 @@ def test_bf16_recomputing_pair_matches_fp32_edge_block(ops, default_routes):
     for a, r, name in zip(res[True][2:], res[False][2:], ("dE", "dw12", "db12", "dQKV", "dye_add", "dye_mul")):
         err = float((a.double() - r.double()).norm() / r.double().norm())
         assert err <= BF16_RTOL, f"{name}: relative L2 error {err:.3e}"
+
+
+# What "within 2e-2" means for a GRADIENT in the bf16 storage mode: relative L2 per tensor, plus at most one element in a
+# thousand further than 2e-2 of the tensor's largest magnitude from the oracle.  Element-wise closeness of every entry is
+# not on offer for any bf16 implementation of this layer: the ~1e-3 perturbation that bf16 storage puts on the edge
+# activations flips the ReLU gate of about one hidden unit in a thousand of the edge feed-forward block, and a flipped gate
+# changes the gradient of its pair row by that whole unit, not by a rounding-sized amount.
+BF16_OUTLIER_FRACTION = 1e-3
+
+
+def test_bf16_storage_layer_matches_the_oracle_within_2e_2(ops, default_routes):
+    """The bf16 storage mode next to the CPU ORACLE (not only next to the fp32 HIP path): one real-width layer on 16 ragged
+    graphs (65 536 pair rows, so every *_bf16 entry point runs), forward and all gradients.  Forward tensors: element-wise
+    within 2e-2 of the tensor's largest magnitude; gradients: 2e-2 in relative L2 and at most BF16_OUTLIER_FRACTION of the
+    entries further than 2e-2 of the largest magnitude."""
+    from oracle import denoiser as O_den
+    got, called = _layer_run(ops, True)
+    assert {"mbvae_edge_fused_fwd_bf16", "mbvae_edge_attn_bwd_bf16", "mbvae_linear_bwd_input_bf16", "mbvae_linear_bwd_weight_bf16"} <= called
+    # the same case on the CPU: _layer_run draws weights and inputs from fixed seeds
+    from mbvae_amd.graph_transformer import XEyTransformerLayer
+    torch.manual_seed(0)
+    layer = XEyTransformerLayer(dx=256, de=64, dy=1024, n_head=8, dim_ffX=256, dim_ffE=128, dim_ffy=1024)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    bs, n = 16, 64
+    mask = _ragged(bs, n, g).cpu()
+    X = torch.randn(bs, n, 256, generator=g).requires_grad_(True)
+    E = torch.randn(bs, n, n, 64, generator=g)
+    E = ((E + E.transpose(1, 2)) / 2).requires_grad_(True)
+    y = torch.randn(bs, 1024, generator=g).requires_grad_(True)
+    cX, cE, cy = (torch.randn(t.shape, generator=g) for t in (X, E, y))
+    oX, oE, oy = O_den.xey_layer(p, X, E, y, mask, 8)
+    ((oX * cX).sum() + (oE * cE).sum() + (oy * cy).sum()).backward()
+    want = dict(oX=oX.detach(), oE=oE.detach(), oy=oy.detach(), dX=X.grad, dE=E.grad, dy=y.grad, **{k: v.grad for k, v in p.items()})
+    report, failures = [], []
+    for k, ref in want.items():
+        a, b = got[k].double().cpu(), ref.double()
+        assert bool(torch.isfinite(a).all()), k
+        scale = max(float(b.abs().max()), 1e-30)
+        d = (a - b).abs()
+        elem = float(d.max()) / scale
+        l2 = float((a - b).norm()) / max(float(b.norm()), 1e-30)
+        far = float((d > BF16_RTOL * scale).double().mean())
+        report.append(f"{k:28s} element-wise {elem:.2e}  L2 {l2:.2e}  entries beyond 2e-2: {far:.1e}")
+        if k in ("oX", "oE", "oy"):
+            if elem > BF16_RTOL:
+                failures.append(f"{k}: element-wise error {elem:.3e} > {BF16_RTOL} of scale")
+        elif l2 > BF16_RTOL or far > BF16_OUTLIER_FRACTION:
+            failures.append(f"{k}: relative L2 {l2:.3e}, {far:.2e} of the entries beyond {BF16_RTOL} of scale")
+    if os.environ.get("MBVAE_TEST_REPORT"):
+        with open(os.environ["MBVAE_TEST_REPORT"], "a") as f:
+            f.write("\n".join(report) + "\n")
+    assert not failures, "\n".join(failures + ["--- all tensors:"] + report)
