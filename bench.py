@@ -114,11 +114,14 @@ def extra_objects():
     return out
 
 
-def launch_workers(n):
+def launch_workers(n, script=None, argv=None, have=None):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes (this same script, one per GPU,
     rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, wait for them, and pass on the worst
-    exit status.  Rank 0 prints the JSON line on the inherited stdout."""
-    have = torch.cuda.device_count()            # (the children are started before this process makes any other GPU call)
+    exit status.  Rank 0 prints the JSON line on the inherited stdout.
+    script / argv / have: the worker program, its arguments and the number of visible GPUs (defaults: this file,
+    this process' arguments, what torch counts) - parameters so that the launcher can be exercised without a GPU."""
+    if have is None:
+        have = torch.cuda.device_count()        # counts devices without initialising the GPU runtime in this process
     if have < n:
         print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible", file=sys.stderr)
         return 2
@@ -130,9 +133,10 @@ def launch_workers(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv),
+                                      env=env))
     codes = [p.wait() for p in procs]
-    return max((abs(c) for c in codes), default=0)
+    return max((abs(c) for c in codes), default=0)      # (a child killed by signal S reports -S)
 
 
 def main():

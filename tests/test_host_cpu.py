@@ -276,3 +276,51 @@ def test_header_lists_every_tuning_switch():
     mentioned = set(re.findall(r"\b((?:NO_|EA_|EF_|EFB_|TSGEMM_|GEMM_)[A-Z0-9_]+)\b", doc))
     assert mentioned <= set(names), mentioned - set(names)
     assert f"The {len(names)} names" in doc
+
+
+def _run_launcher(tmp_path, n, have, extra=()):
+    """bench.launch_workers in a child process (so its inherited stdout can be captured) with the stub worker."""
+    import json
+    import subprocess
+    stub = os.path.join(ROOT, "tests", "helpers", "launch_stub_worker.py")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"sys.exit(bench.launch_workers({n}, script={stub!r}, argv={[str(tmp_path)] + list(extra)!r}, have={have}))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    seen = {}
+    for name in os.listdir(tmp_path):
+        with open(os.path.join(tmp_path, name)) as f:
+            seen[name] = json.load(f)
+    return r, seen
+
+
+def test_bench_launcher_gives_every_worker_its_rank_and_one_rendezvous(tmp_path):
+    """`python bench.py --gpus N` without torchrun: N workers, ranks 0..N-1 once each, one shared 127.0.0.1 rendezvous port,
+    the dmabuf IPC switch set, the caller's arguments passed through, exactly one JSON line on stdout (rank 0's)."""
+    import json
+    r, seen = _run_launcher(tmp_path, 4, have=8, extra=("--steps", "3"))
+    assert r.returncode == 0, r.stderr
+    assert sorted(seen) == [f"rank{i}.json" for i in range(4)]
+    ports = set()
+    for i in range(4):
+        env = seen[f"rank{i}.json"]["env"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(i)
+        assert env["WORLD_SIZE"] == env["LOCAL_WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ports.add(env["MASTER_PORT"])
+        assert seen[f"rank{i}.json"]["argv"] == [str(tmp_path), "--steps", "3"]
+    assert len(ports) == 1 and 1024 <= int(next(iter(ports))) < 65536
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "stub", "n_gpus": 4}
+
+
+def test_bench_launcher_passes_on_the_worst_exit_status_and_refuses_missing_gpus(tmp_path):
+    """One failing rank fails the job with that rank's code (the others are still waited for); asking for more GPUs
+    than are visible starts nothing and returns 2."""
+    r, seen = _run_launcher(tmp_path, 3, have=3, extra=("--exit", "1:7"))
+    assert r.returncode == 7 and len(seen) == 3
+    sub = tmp_path / "none"
+    sub.mkdir()
+    r, seen = _run_launcher(sub, 4, have=2)
+    assert r.returncode == 2 and not seen and "4 requested but 2" in r.stderr.replace("--gpus ", "")

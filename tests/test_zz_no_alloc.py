@@ -27,9 +27,13 @@ def test_masked_ce_static_scratch_matches_workspace_entry_point():
         want = torch.full((18,), -7.0, device="cuda")
         got = torch.full((18,), -9.0, device="cuda")
         _lib.call("mbvae_masked_ce_fwd", logits.data_ptr(), target.data_ptr(), want.data_ptr(), rows, C, ws.data_ptr(), ws.numel(), st)
-        before = torch.cuda.memory_allocated()
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()          # torch's allocator ...
+        free_before = torch.cuda.mem_get_info()[0]       # ... and the device itself: a hipMalloc inside the library shows here
         _lib.call("mbvae_masked_ce_fwd_static", logits.data_ptr(), target.data_ptr(), got.data_ptr(), rows, C, st)
+        torch.cuda.synchronize()
         assert torch.cuda.memory_allocated() == before
+        assert torch.cuda.mem_get_info()[0] == free_before, "device memory changed across the allocation-free entry point"
         assert torch.equal(got, want), f"rows={rows}: {got.tolist()} vs {want.tolist()}"
         ref = F.cross_entropy(logits[target.sum(1) > 0].double().cpu(), target[target.sum(1) > 0].argmax(1).cpu(), reduction="sum")
         assert abs(float(got[0]) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1e-30) and int(got[1]) == int((target.sum(1) > 0).sum())
