@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the second, labelled bf16-storage measurement")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--one-stream", action="store_true", help="A/B aid: the whole step on one HIP stream (not the headline mode)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the additional labelled objects (sampling, encoder step, joint step; N = 1 only)")
     args = ap.parse_args()
@@ -171,7 +172,8 @@ def main():
 
     # second stream for the node / global-feature kernels (bit-identical to one stream, tests/test_gpu_two_streams.py);
     # on one GPU the weight update additionally runs on it under the next step's noising and graph features
-    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0, side_stream=True, overlap_optimizer=world == 1)
+    trainer = DenoiserTrainStep(CFG3, device=dev, distributed=world > 1, seed=0, side_stream=not args.one_stream,
+                                overlap_optimizer=world == 1 and not args.one_stream)
     g = torch.Generator().manual_seed(1000 + rank)          # a different data shard per rank
     bs, n = args.batch, args.nodes
     X0, E0, mask = synthetic_graphs(bs, n, dev, g)
@@ -214,7 +216,7 @@ def main():
         torch.cuda.synchronize()
     finally:
         _lib.PROFILE = None
-        ops.set_side_stream(True)
+        ops.set_side_stream(not args.one_stream)
     # second, separately labelled measurement (N = 1 only): the opt-in bf16 STORAGE mode of the edge block's large
     # activations (fp32 weights and arithmetic; parity bound 2e-2 instead of 1e-5).  Never the headline `value`.
     bf16_line = None

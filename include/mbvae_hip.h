@@ -33,19 +33,20 @@ typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
 /* ---- tuning switches ------------------------------------------------------------------------------------
  * No counterpart in the reference.  Process-wide switches that choose between equivalent HIP routes (kernel A/B
  * timing, parity tests of the fallback kernels; never a CPU path).  Each starts from the environment variable
- * MBVAE_<NAME>, read once.  The 24 names (0 / 1 unless a range is given):
+ * MBVAE_<NAME>, read once.  The 25 names (0 / 1 unless a range is given):
  *   kernel families   NO_TSGEMM, NO_TSGEMM2 (tall-skinny products over the pair rows), TSGEMM_N64, NO_TSWGRAD, NO_TSWGRAD2
  *                     (their weight gradients), NO_SMALLM (few-tile products of the global-feature path), NO_COLGROUPS
  *                     (node-path column groups), NO_THIN (the 5-wide ends of the edge MLPs), GEMM_TILE (-1 automatic,
- *                     0 = 64x64, 1 = 128x64, 2 = 128x128 tiles of the generic kernel)
+ *                     0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 32x128, 4 = 64x128 tiles of the generic kernel)
  *   arithmetic        NO_SPLIT_MFMA (edge-path products on the native fp32 matrix instructions instead of six bf16 ones)
  *   attention block   NO_EDGE_FUSED, NO_EDGE_TRAIN_FUSED, NO_E12_RECOMPUTE (store e_mul|e_add instead of recomputing it in
  *                     the backward), NO_EF_COOP / NO_EFB_COOP (operand tile split per wave instead of once per
  *                     workgroup, forward / backward), EF_STAGGER (0..3: how the waves of a workgroup are phased),
  *                     EFB_SYNC (rendezvous period of the recomputing backward in query rows, power of two; 0 = 8),
  *                     EA_KEYS (8, else 16 keys per wave in the storing attention backward), NO_EA_PREFETCH
- *   fusions           NO_EDGE_FFN (inference feed-forward block), NO_LN_EPILOGUE (Linear + LayerNorm), NO_BWD_BOTH (both
- *                     gradients of e_mul|e_add from one pass), NO_FFN_HANDOVER and NO_FILM (read by the host side)
+ *   fusions           NO_EDGE_FFN (inference feed-forward block), NO_EDGE_FFN_TRAIN (its training form), NO_LN_EPILOGUE
+ *                     (Linear + LayerNorm), NO_BWD_BOTH (both gradients of e_mul|e_add from one pass), NO_FFN_HANDOVER
+ *                     and NO_FILM (read by the host side)
  * mbvae_set_option: 0, or -1 for an unknown name.  mbvae_get_option: the value (-1 for an unknown name; GEMM_TILE's
  * "automatic" is -1 as well).  A change takes effect at the next entry-point call. */
 int mbvae_set_option(const char* name, int value);
@@ -183,6 +184,28 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
                        const float* gamma, const float* beta, float* out, const uint8_t* tile_ok,
                        const int32_t* row_idx, const int32_t* nvalid, int64_t M, int64_t d, int64_t dff, float eps,
                        mbvae_stream_t stream);
+
+/* Training form of the same block (graph_transformer.py:139-142 with dropoutE2 / dropoutE3 active), one pass over the rows:
+ *   hidden [M,dff] = dropout_p1(relu(x W1^T + b1)),  z [M,d] = x + dropout_p2(hidden W2^T + b2),  out = LayerNorm(z) * gamma + beta.
+ * hidden and z are what the backward reads (mbvae_ln_sum_bwd on z, then mbvae_linear_bwd_input_outgate / _bwd_weight /
+ * _bwd_input_add on hidden and x): dropout keep-scales are hashed from (seed, row * width + column) exactly as
+ * mbvae_linear_fwd (seed1, width dff) and mbvae_linear_ln_fwd (seed2, width d) hash them.  Per row 256 B are read and
+ * 1 KB written; the two separate kernels read 1 KB and write 1 KB.  MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M a
+ * multiple of 32 and M * dff < 2^32: callers then use mbvae_linear_fwd and mbvae_linear_ln_fwd. */
+int mbvae_edge_ffn_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* gamma, const float* beta, float* hidden, float* z, float* out, int64_t M,
+                             int64_t d, int64_t dff, float eps, float p1, uint64_t seed1, float p2, uint64_t seed2,
+                             mbvae_stream_t stream);
+
+/* Backward data path of the block (autograd of graph_transformer.py:139-142 with respect to the activations), one pass:
+ *   dh [M,dff] = (h > 0 ? dr W2 : 0) * gate_scale,   dx [M,d] = dh W1 + dres
+ * dr / dres [M,d]: the gradient entering linE2's output and the residual branch's (what mbvae_ln_sum_bwd returns; the same
+ * pointer when dropoutE3 is off); h: the hidden activation stored by mbvae_edge_ffn_fwd_train, whose sign pattern is the
+ * ReLU-and-dropout gate (gate_scale = 1 / (1 - p1)).  The weight gradients come from mbvae_linear_bwd_weight on (dr, h) and
+ * (dh, x).  MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M a multiple of 32: callers then use
+ * mbvae_linear_bwd_input_outgate and mbvae_linear_bwd_input_add. */
+int mbvae_edge_ffn_bwd_data(const float* dr, const float* dres, const float* h, const float* W1, const float* W2,
+                            float* dh, float* dx, int64_t M, int64_t d, int64_t dff, float gate_scale, mbvae_stream_t stream);
 
 /* Inference form of `normE1(E + e_out(newE))` (graph_transformer.py:251-252 followed by :133-134): out [M,de] =
  * LayerNorm(E + keep(row) * (P W^T + b)) * gamma + beta, P [M,dx], W [de,dx] (torch Linear layout), b [de] or NULL,

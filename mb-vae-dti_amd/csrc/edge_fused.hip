@@ -643,10 +643,17 @@ __device__ __forceinline__ mbvae_bf16x8 ef_ld44(const unsigned short* p) {
     acc = MBVAE_MFMA_BF16(wm_, xs.hi, acc); acc = MBVAE_MFMA_BF16(wh_, xs.mid, acc); acc = MBVAE_MFMA_BF16(wh_, xs.hi, acc); \
   }
 
+// 16-byte store.  Plain on purpose: each lane writes 32-byte pieces of its own row, which the L2 assembles into whole
+// lines; with the non-temporal hint the same stores ran 2.6 times slower (measured, 1 M rows).
+#define EF_ST4(ptr, v4) (*reinterpret_cast<float4*>(ptr) = (v4))
+
 struct EdgeFfnArgs {
   const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
   const float* gamma; const float* beta; float* out; int64_t M; float eps; const uint8_t* tile_ok;
   const int32_t* row_idx; const int32_t* nvalid;   // packed row order (see ef_row_order), or null
+  // training form: the hidden activation after ReLU / dropout [M,128] and the pre-LayerNorm sum [M,64] are stored for
+  // the backward; dropout keep-scales are hashed from (seed, row * width + column) as in the separate Linear kernels
+  float* hidden; float* z; float p1, p2; uint64_t seed1, seed2;
 };
 
 // Packed row order for ragged batches (optional, both kernels below): row_idx lists the nvalid[0] valid rows, padded
@@ -713,7 +720,9 @@ struct EfTileWindow {
 // are split once, at staging time, into three bf16 planes per matrix, rows padded by 16 bytes so that the A-operand
 // fetches are conflict-free; the activations (x rows, then the ReLU'd hidden accumulators - eight consecutive
 // accumulator registers ARE one B-operand octet) are split in registers, once per 16 reduction indices.
-template <bool SPLIT>
+// TRAIN: dropout (p1) on the hidden activation and (p2) on the second Linear's output; the hidden activation and the
+// pre-LayerNorm sum are written out (once each, never read back here) for the backward kernels.
+template <bool SPLIT, bool TRAIN = false>
 __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   constexpr int L1 = 65, L2 = 129;                  // LDS row strides of W1 [128][64] and W2 [64][128]
   constexpr int K1 = 72, K2 = 136;                  // SPLIT: bf16 elements per row of the W1 / W2 planes
@@ -820,6 +829,23 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
       }                                                                                                \
     }                                                                                                  \
     }                                                                                                  \
+    if (TRAIN) {                 /* ReLU + dropout in place, then the hidden row goes out: 16 x 16 bytes per lane */ \
+      const unsigned hbase = (unsigned)srow[S] * 128u + 4u * h;                                        \
+      float* hrow = a.hidden + (int64_t)srow[S] * 128 + 4 * h;                                         \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                             \
+          float4 o;                                                                                    \
+          o.x = fmaxf(hh[t][4 * gq + 0], 0.f); o.y = fmaxf(hh[t][4 * gq + 1], 0.f);                    \
+          o.z = fmaxf(hh[t][4 * gq + 2], 0.f); o.w = fmaxf(hh[t][4 * gq + 3], 0.f);                    \
+          if (a.p1 > 0.f) {                                                                            \
+            const unsigned i0 = hbase + 32 * t + 8 * gq;                                               \
+            o.x *= mbvae_drop_scale(a.p1, a.seed1, i0); o.y *= mbvae_drop_scale(a.p1, a.seed1, i0 + 1); \
+            o.z *= mbvae_drop_scale(a.p1, a.seed1, i0 + 2); o.w *= mbvae_drop_scale(a.p1, a.seed1, i0 + 3); \
+          }                                                                                            \
+          hh[t][4 * gq + 0] = o.x; hh[t][4 * gq + 1] = o.y; hh[t][4 * gq + 2] = o.z; hh[t][4 * gq + 3] = o.w; \
+          if (sinb[S]) EF_ST4(hrow + 32 * t + 8 * gq, o);                                              \
+        }                                                                                              \
+    }                                                                                                  \
     /* output layer: the (ReLU'd) hidden registers are the B operand */                                \
     f32x16 yy[2];                                                                                      \
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
@@ -853,8 +879,17 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
     _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
       _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                               \
         const float4 xr = xres[4 * u + gq];                                                            \
+        if (TRAIN && a.p2 > 0.f) {                                                                     \
+          const unsigned i0 = (unsigned)srow[S] * 64u + 4u * h + 32 * u + 8 * gq;                      \
+          yy[u][4 * gq + 0] *= mbvae_drop_scale(a.p2, a.seed2, i0); yy[u][4 * gq + 1] *= mbvae_drop_scale(a.p2, a.seed2, i0 + 1); \
+          yy[u][4 * gq + 2] *= mbvae_drop_scale(a.p2, a.seed2, i0 + 2); yy[u][4 * gq + 3] *= mbvae_drop_scale(a.p2, a.seed2, i0 + 3); \
+        }                                                                                              \
         z[u][4 * gq + 0] = yy[u][4 * gq + 0] + xr.x; z[u][4 * gq + 1] = yy[u][4 * gq + 1] + xr.y;      \
         z[u][4 * gq + 2] = yy[u][4 * gq + 2] + xr.z; z[u][4 * gq + 3] = yy[u][4 * gq + 3] + xr.w;      \
+        if (TRAIN && sinb[S]) {                                                                        \
+          float4 zo; zo.x = z[u][4 * gq]; zo.y = z[u][4 * gq + 1]; zo.z = z[u][4 * gq + 2]; zo.w = z[u][4 * gq + 3]; \
+          EF_ST4(a.z + (int64_t)srow[S] * 64 + 4 * h + 32 * u + 8 * gq, zo);                           \
+        }                                                                                              \
         sum += (z[u][4 * gq] + z[u][4 * gq + 1]) + (z[u][4 * gq + 2] + z[u][4 * gq + 3]);              \
       }                                                                                                \
     sum += __shfl_xor(sum, 32);                                                                        \
@@ -886,6 +921,124 @@ __global__ __launch_bounds__(512) void edge_ffn_fwd_kernel(EdgeFfnArgs a) {
   }
 #undef FF_FETCH
 #undef FF_TILE
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward data path of the same block in one pass over the rows (training):
+//   dh [M,128] = (h > 0 ? dr W2 : 0) * gate_scale        (h = the stored hidden activation: ReLU and dropout gate in one)
+//   dx [M,64]  = dh W1 + dres                              (dres = gradient of the residual branch)
+// with dr, dres [M,64] (the same tensor when the output dropout is off).  Same transposed products as the forward (rows
+// on the lanes): first the hidden units of one 32-unit tile at a time - its accumulators are gated, stored and fed
+// straight into the second product as the B operand - so only 16 hidden accumulators are live.  The weight planes in
+// LDS are the TRANSPOSES of the forward's (W2^T as [unit][out], W1^T as [in][unit]).  Separate kernels read dr, h, dh and
+// dres (2.3 KB per row in all) and write dh, dx; here 1.25 KB are read.  The weight gradients stay with their kernels.
+struct EdgeFfnBwdArgs {
+  const float* dr; const float* dres; const float* h; const float* W1; const float* W2;
+  float* dh; float* dx; int64_t M; float gate_scale;
+};
+
+__global__ __launch_bounds__(512) void edge_ffn_bwd_kernel(EdgeFfnBwdArgs a) {
+  constexpr int K1 = 72, K2 = 136;                  // bf16 elements per row of the two plane sets
+  extern __shared__ __align__(16) float fb_lds[];
+  unsigned short* P1 = reinterpret_cast<unsigned short*>(fb_lds);      // [3][128 units][K1]: W2^T
+  unsigned short* P2 = P1 + 3 * 128 * K1;                              // [3][64 inputs][K2]: W1^T
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 128 * 64; e += 512) {
+    ef_store_planes(P1 + (e & 127) * K1 + (e >> 7), 128 * K1, a.W2[e]);      // W2[o = e >> 7][u = e & 127]
+    ef_store_planes(P2 + (e & 63) * K2 + (e >> 6), 64 * K2, a.W1[e]);        // W1[u = e >> 6][k = e & 63]
+  }
+  __syncthreads();
+  const int64_t ntiles = a.M / 32;
+  const int64_t wid = (int64_t)blockIdx.x * 8 + wave, nw = (int64_t)gridDim.x * 8;
+  const int64_t mine = wid < ntiles ? (ntiles - wid + nw - 1) / nw : 0;
+  if (mine <= 0) return;
+  const float gs = a.gate_scale;
+  float4 ra[8];
+#define FB_FETCH(q)                                                                                    \
+  {                                                                                                   \
+    const int64_t row = (wid + min((int64_t)(q), mine - 1) * nw) * 32 + r;                             \
+    const float* src = a.dr + row * 64 + 32 * h;                                                       \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) ra[p] = ef_ld4(src + 4 * p);                         \
+    asm volatile("" : : : "memory");                                                                   \
+  }
+  FB_FETCH(0)
+  for (int64_t q = 0; q < mine; ++q) {
+    const int64_t row = (wid + q * nw) * 32 + r;
+    const float* hrow = a.h + row * 128 + 4 * h;
+    float* dhrow = a.dh + row * 128 + 4 * h;
+    // a zero the optimiser cannot see through (keeps loop-invariant LDS addresses out of registers)
+    int oz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    const int h4 = 4 * h + oz;
+    // the second product's accumulators start at the residual branch's gradient (their layout: columns 32u + 8g + 4h + 0..3)
+    f32x16 yy[2];
+    {
+      const float* rrow = a.dres + row * 64 + 4 * h;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 t4 = ef_ld4(rrow + 32 * u + 8 * gq);
+          yy[u][4 * gq] = t4.x; yy[u][4 * gq + 1] = t4.y; yy[u][4 * gq + 2] = t4.z; yy[u][4 * gq + 3] = t4.w;
+        }
+    }
+    float4 hg[2][4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) hg[0][gq] = ef_ld4(hrow + 8 * gq);
+    asm volatile("" : : : "memory");
+    MbvaeSplit3 xs[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float4 t4 = ra[2 * o], u4 = ra[2 * o + 1];
+      asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w), "+v"(u4.x), "+v"(u4.y), "+v"(u4.z), "+v"(u4.w) : : "memory");
+      xs[o] = mbvae_split8(t4.x, t4.y, t4.z, t4.w, u4.x, u4.y, u4.z, u4.w);
+    }
+    FB_FETCH(q + 1)                                   // the operand registers are free again: next tile's rows
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < 3) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) hg[(t + 1) & 1][gq] = ef_ld4(hrow + 32 * (t + 1) + 8 * gq);
+        asm volatile("" : : : "memory");
+      }
+      f32x16 hh;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) hh[v] = 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const unsigned short* wp = P1 + (32 * t + r) * K1 + 32 * h + 8 * o + oz;     // W2^T[unit r + 32t][out octet]
+        EF_SPLIT_MFMA(hh, ef_ld8(wp), ef_ld8(wp + 128 * K1), ef_ld8(wp + 2 * 128 * K1), xs[o])
+      }
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 g4 = hg[t & 1][gq];
+        float4 o4;
+        o4.x = g4.x > 0.f ? hh[4 * gq] * gs : 0.f;     o4.y = g4.y > 0.f ? hh[4 * gq + 1] * gs : 0.f;
+        o4.z = g4.z > 0.f ? hh[4 * gq + 2] * gs : 0.f; o4.w = g4.w > 0.f ? hh[4 * gq + 3] * gs : 0.f;
+        hh[4 * gq] = o4.x; hh[4 * gq + 1] = o4.y; hh[4 * gq + 2] = o4.z; hh[4 * gq + 3] = o4.w;
+        *reinterpret_cast<float4*>(dhrow + 32 * t + 8 * gq) = o4;
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const MbvaeSplit3 hs = mbvae_split8(hh[8 * gp], hh[8 * gp + 1], hh[8 * gp + 2], hh[8 * gp + 3], hh[8 * gp + 4], hh[8 * gp + 5],
+                                            hh[8 * gp + 6], hh[8 * gp + 7]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned short* wp = P2 + (32 * u + r) * K2 + 32 * t + 16 * gp + h4;   // W1^T[input r + 32u][unit octet]
+          EF_SPLIT_MFMA(yy[u], ef_ld44(wp), ef_ld44(wp + 64 * K2), ef_ld44(wp + 2 * 64 * K2), hs)
+        }
+      }
+    }
+    float* orow = a.dx + row * 64 + 4 * h;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(orow + 32 * u + 8 * gq) = make_float4(yy[u][4 * gq], yy[u][4 * gq + 1], yy[u][4 * gq + 2], yy[u][4 * gq + 3]);
+  }
+#undef FB_FETCH
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1248,13 +1401,64 @@ int mbvae_edge_ffn_fwd(const float* x, const float* W1, const float* b1, const f
   const void* ptrs[] = {x, W1, W2, gamma, beta, out};
   for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
   if ((row_idx == nullptr) != (nvalid == nullptr) || (row_idx && M < 32)) return MBVAE_EINVAL;
-  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid};
+  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, tile_ok, row_idx, nvalid, nullptr, nullptr, 0.f, 0.f, 0, 0};
   const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
   const size_t smem = split ? 2 * 3 * (128 * 72 + 64 * 136) + sizeof(float) * (128 + 3 * 64 + 8 * 64)
                             : sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
   if (!(split ? MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel<true>) : MBVAE_ALLOW_BIG_LDS(edge_ffn_fwd_kernel<false>))) return MBVAE_ELAUNCH;
   const int grid = (int)std::min<int64_t>(((M + 31) / 32 + 1 + 7) / 8, ef_num_cus());   // (+1: the packed order may add a tile)
   hipLaunchKernelGGL(split ? edge_ffn_fwd_kernel<true> : edge_ffn_fwd_kernel<false>, dim3(grid), dim3(512), smem, stream, a);
+  return mbvae_launch_status();
+}
+
+// Training form of the same block, one pass over the rows:
+//   hidden [M,128] = dropout_p1(relu(x W1^T + b1))                      (stored for the backward)
+//   z      [M,64]  = x + dropout_p2(hidden W2^T + b2)                   (stored for the backward: the LayerNorm's input)
+//   out    [M,64]  = LayerNorm(z) * gamma + beta
+// Dropout keep-scales are hashed from (seed, row * width + column) exactly as mbvae_linear_fwd / mbvae_linear_ln_fwd
+// hash them, so the backward entry points of those (mbvae_ln_sum_bwd, mbvae_linear_bwd_input_outgate, ...) apply
+// unchanged.  Per row 256 B are read and 1 KB written; the two separate kernels read 1 KB and write 1 KB.
+// MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M a multiple of 32 with M * 128 < 2^32.
+int mbvae_edge_ffn_fwd_train(const float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* gamma, const float* beta, float* hidden, float* z, float* out, int64_t M,
+                             int64_t d, int64_t dff, float eps, float p1, uint64_t seed1, float p2, uint64_t seed2,
+                             hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (M <= 0 || !(p1 >= 0.f && p1 < 1.f) || !(p2 >= 0.f && p2 < 1.f)) return MBVAE_EINVAL;
+  if (d != 64 || dff != 128 || (M & 31) || M * 128 > 0xffffffffll || mbvae_opt(MBVAE_OPT_NO_EDGE_FFN_TRAIN)) return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {x, W1, W2, gamma, beta, hidden, z, out};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  EdgeFfnArgs a{x, W1, b1, W2, b2, gamma, beta, out, M, eps, nullptr, nullptr, nullptr, hidden, z, p1, p2, seed1, seed2};
+  const bool split = !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA);
+  const size_t smem = split ? 2 * 3 * (128 * 72 + 64 * 136) + sizeof(float) * (128 + 3 * 64 + 8 * 64)
+                            : sizeof(float) * (128 * 65 + 64 * 129 + 128 + 3 * 64 + 8 * 64);
+  if (!(split ? MBVAE_ALLOW_BIG_LDS((edge_ffn_fwd_kernel<true, true>)) : MBVAE_ALLOW_BIG_LDS((edge_ffn_fwd_kernel<false, true>)))) return MBVAE_ELAUNCH;
+  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  if (split) hipLaunchKernelGGL((edge_ffn_fwd_kernel<true, true>), dim3(grid), dim3(512), smem, stream, a);
+  else hipLaunchKernelGGL((edge_ffn_fwd_kernel<false, true>), dim3(grid), dim3(512), smem, stream, a);
+  return mbvae_launch_status();
+}
+
+// Backward data path of that block in one pass: dh [M,128] = (h > 0 ? dr W2 : 0) * gate_scale, dx [M,64] = dh W1 + dres.
+// dr / dres [M,64]: the gradient entering the second Linear's output and the one of the residual branch (what
+// mbvae_ln_sum_bwd returns; the same pointer when the output dropout is off); h [M,128]: the hidden activation stored by
+// the forward (its sign pattern is the ReLU-and-dropout gate; gate_scale = 1 / (1 - p1)).  W1 [128,64], W2 [64,128].
+// MBVAE_EUNSUPPORTED unless d == 64, dff == 128, M a multiple of 32 (and with the fp32-MFMA switch on): callers then use
+// mbvae_linear_bwd_input_outgate and mbvae_linear_bwd_input_add.
+int mbvae_edge_ffn_bwd_data(const float* dr, const float* dres, const float* h, const float* W1, const float* W2,
+                            float* dh, float* dx, int64_t M, int64_t d, int64_t dff, float gate_scale, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
+  if (M <= 0) return MBVAE_EINVAL;
+  if (d != 64 || dff != 128 || (M & 31) || M * 128 > 0xffffffffll || mbvae_opt(MBVAE_OPT_NO_EDGE_FFN_TRAIN) ||
+      mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA))
+    return MBVAE_EUNSUPPORTED;
+  const void* ptrs[] = {dr, dres, h, W1, W2, dh, dx};
+  for (const void* p : ptrs) if (!p || ((uintptr_t)p & 15)) return MBVAE_EINVAL;
+  EdgeFfnBwdArgs a{dr, dres, h, W1, W2, dh, dx, M, gate_scale};
+  const size_t smem = 2 * 3 * (128 * 72 + 64 * 136);
+  if (!MBVAE_ALLOW_BIG_LDS(edge_ffn_bwd_kernel)) return MBVAE_ELAUNCH;
+  const int grid = (int)std::min<int64_t>((M / 32 + 7) / 8, ef_num_cus());
+  hipLaunchKernelGGL(edge_ffn_bwd_kernel, dim3(grid), dim3(512), smem, stream, a);
   return mbvae_launch_status();
 }
 

@@ -2139,8 +2139,8 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   else { BM = 128; BN = 128; }
   // fewer than two big tiles per CU leave the chip under-filled and every block latency bound: use small tiles
   if (BM == 128 && (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) < 2 * ts_num_cus()) { BM = 64; BN = 64; }
-  if (const int f = mbvae_opt(MBVAE_OPT_GEMM_TILE); f >= 0) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128
-    BM = f == 0 ? 64 : 128; BN = f == 2 ? 128 : 64;
+  if (const int f = mbvae_opt(MBVAE_OPT_GEMM_TILE); f >= 0) {           // tuning aid: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 32x128, 4 = 64x128
+    BM = f == 0 || f == 4 ? 64 : (f == 3 ? 32 : 128); BN = f >= 2 ? 128 : 64;
   }
   const int64_t tiles = (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
@@ -2173,7 +2173,9 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
     else if (gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, true>), grid, block, 0, stream, g);          \
     else hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, false>), grid, block, 0, stream, g);                   \
   } while (0)
-  if (BM == 64) GEMM_LAUNCH(64, 64, 2, 2);
+  if (BM == 32) GEMM_LAUNCH(32, 128, 1, 4);
+  else if (BM == 64 && BN == 128) GEMM_LAUNCH(64, 128, 2, 2);
+  else if (BM == 64) GEMM_LAUNCH(64, 64, 2, 2);
   else if (BN == 64) GEMM_LAUNCH(128, 64, 4, 1);
   else GEMM_LAUNCH(128, 128, 2, 2);
 #undef GEMM_LAUNCH

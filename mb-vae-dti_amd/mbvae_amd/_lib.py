@@ -40,6 +40,8 @@ SIGNATURES = {
     "mbvae_edge_fused_bwd_bf16": [_P] * 6 + [_L] + [_P] * 12 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_fused_fwd_bf16": [_P] * 6 + [_L] + [_P] * 7 + [_L, _L, _L, _L, _F, _P],
     "mbvae_edge_ffn_fwd": [_P] * 11 + [_L, _L, _L, _F, _P],
+    "mbvae_edge_ffn_fwd_train": [_P] * 10 + [_L, _L, _L, _F, _F, _U, _F, _U, _P],
+    "mbvae_edge_ffn_bwd_data": [_P] * 7 + [_L, _L, _L, _F, _P],
     "mbvae_edge_out_ln_fwd": [_P] * 5 + [_L] + [_P] * 6 + [_I, _L, _L, _L, _F, _P],
     "mbvae_ln_residual_fwd": [_P] * 7 + [_L, _L, _F, _F, _U, _P],
     "mbvae_linear_ln_fwd": [_P, _L] + [_P] * 7 + [_L, _L, _L, _P, _I, _I, _F, _F, _U, _P],

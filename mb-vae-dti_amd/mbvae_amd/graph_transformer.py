@@ -14,6 +14,11 @@ from . import ops
 from .containers import PlaceHolder
 
 
+# Diagnostic (tools/critical_lane_probe.py): ("E" | "N", cycles) puts a one-thread spin kernel of that many clock cycles into
+# every layer's forward on the edge-tensor stream or on the node / global stream: the lane whose delay shows up in the
+# step time is the one the step waits for.  None in normal use.
+LANE_DELAY = None
+
 class _SeedStream:
     """Per-forward stream of dropout seeds derived from torch's CPU generator (no device sync)."""
 
@@ -217,7 +222,11 @@ class XEyTransformerLayer(nn.Module):
 
         sXf, sEf, syf = [(seeds.next(), seeds.next()) for _ in range(3)]      # seeds in the order X, E, y use them
         if side is not None:
+            if LANE_DELAY is not None and LANE_DELAY[0] == "E":
+                torch.cuda._sleep(LANE_DELAY[1])
             with torch.cuda.stream(side):
+                if LANE_DELAY is not None and LANE_DELAY[0] == "N":
+                    torch.cuda._sleep(LANE_DELAY[1])
                 X, y = norm(self.normX1, X, newX, sX1), norm(self.norm_y1, y, new_y, sy1)
                 X = ff_block(self.normX2, self.linX1, self.linX2, X, *sXf)
                 y = ff_block(self.norm_y2, self.lin_y1, self.lin_y2, y, *syf)

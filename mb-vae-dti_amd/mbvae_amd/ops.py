@@ -87,7 +87,7 @@ def side_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        st = _side_streams[key] = torch.cuda.Stream(device=device)      # (a high-priority stream measured the same)
     return st
 
 
@@ -221,6 +221,78 @@ def linear(x, weight, bias=None, act=0, mask=None, mask_mode=MASK_NONE, n_nodes=
     return _Linear.apply(x, weight, bias, act, mask, mask_mode, n_nodes, drop_p, seed, with_alias, in_gate_scale, pregated)
 
 
+class _FfnLn(torch.autograd.Function):
+    """LayerNorm(x + dropout(l2(dropout(relu(l1(x)))))) of the edge tensor in ONE forward kernel
+    (mbvae_edge_ffn_fwd_train): the hidden activation and the pre-LayerNorm sum are written once for the backward and
+    never read back in the forward.  The backward is the one of _Linear (l1, gate handed over) followed by _LinearLn
+    (l2), run from here on the stored tensors: same kernels, same dropout masks."""
+
+    class _LinCtx:                       # what _Linear.backward reads from its ctx
+        pass
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, seed1, p2, seed2):
+        x2 = _f32c(x, "x").reshape(-1, x.shape[-1])
+        w1, w2, gamma, beta = _f32c(w1, "weight"), _f32c(w2, "weight"), _f32c(gamma), _f32c(beta)
+        M, d = x2.shape
+        dff = w1.shape[0]
+        h = torch.empty((M, dff), dtype=torch.float32, device=x.device)
+        z, y = torch.empty_like(x2), torch.empty_like(x2)
+        _lib.call("mbvae_edge_ffn_fwd_train", x2.data_ptr(), w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2), gamma.data_ptr(),
+                  beta.data_ptr(), h.data_ptr(), z.data_ptr(), y.data_ptr(), M, d, dff, float(eps), float(p1), int(seed1),
+                  float(p2), int(seed2), _stream(), tag=(M, d, dff))
+        ctx.save_for_backward(x2, w1, w2, h, z, gamma)
+        ctx.cfg = (float(eps), float(p1), float(p2), int(seed2), b1 is not None, b2 is not None, x.shape)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, z, gamma = ctx.saved_tensors
+        eps, p1, p2, seed2, has_b1, has_b2, xshape = ctx.cfg
+        rows, D = z.shape
+        dy = _f32c(dy, "dy")
+        dres = torch.empty_like(z)
+        dr = torch.empty_like(z) if p2 > 0 else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = workspace(z.device)
+        _lib.call("mbvae_ln_sum_bwd", z.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dres.data_ptr(), _ptr(dr),
+                  dgamma.data_ptr(), dbeta.data_ptr(), rows, D, eps, p2, seed2, ws.data_ptr(), ws.numel(), _stream())
+        need = ctx.needs_input_grad
+        gscale = 1.0 / (1.0 - p1) if p1 > 0 else 1.0
+        dlin = dr if dr is not None else dres
+        # activations' gradients in one pass: dh (l1's ReLU / dropout gate applied, h itself is the gate) and dx
+        dh = torch.empty_like(h)
+        dx = torch.empty_like(x2)
+        fused = _lib.call("mbvae_edge_ffn_bwd_data", dlin.data_ptr(), dres.data_ptr(), h.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                          dh.data_ptr(), dx.data_ptr(), rows, D, h.shape[1], gscale, _stream(), tag=(rows, D, h.shape[1]),
+                          allow_unsupported=True)
+        lin2 = _FfnLn._LinCtx()          # l2: weight / bias gradients (and dh, gated in the product's epilogue, if not fused)
+        lin2.saved_tensors = (h, w2, None, None)
+        lin2.cfg = (MASK_NONE, 0, 0.0, False, has_b2, h.shape)
+        lin2.in_gate_scale, lin2.relu = gscale, False
+        lin2.needs_input_grad = (not fused, need[3], need[4])
+        dh2, dw2, db2 = _Linear.backward(lin2, dlin)[:3]
+        if not fused:
+            dh = dh2
+        lin1 = _FfnLn._LinCtx()          # l1: dh arrives gated; unfused, the residual branch's gradient joins in its epilogue
+        lin1.saved_tensors = (x2, w1, None, None)
+        lin1.cfg = (MASK_NONE, 0, p1, False, has_b1, xshape)
+        lin1.in_gate_scale, lin1.relu = None, True
+        lin1.needs_input_grad = (need[0] and not fused, need[1], need[2])
+        dx1, dw1, db1 = _Linear.backward(lin1, dh, dres)[:3]
+        dx = (dx.reshape(xshape) if need[0] else None) if fused else dx1
+        return dx, dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None
+
+
+def ffn_ln_train_supported(x, w1, w2):
+    """Shapes mbvae_edge_ffn_fwd_train takes: the edge tensor's feed-forward block (64 -> 128 -> 64) over >= 32768 rows."""
+    M = x.numel() // x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 64 and tuple(w1.shape) == (128, 64) and tuple(w2.shape) == (64, 128)
+            and M >= 32768 and M % 32 == 0 and M * 128 < 0x3fffffff
+            and not (option_set("NO_EDGE_FFN_TRAIN") or option_set("NO_FFN_HANDOVER") or option_set("NO_LN_EPILOGUE")
+                     or option_set("NO_TSGEMM") or option_set("NO_TSGEMM2")))
+
+
 def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None, ln=None):
     """(l2(dropout(relu(l1(x)))), alias of x for the residual branch): the two Linears of a feed-forward block
     (graph_transformer.py:139-146).  The hidden activation h has exactly one consumer, so with `handover` the ReLU /
@@ -229,9 +301,13 @@ def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None, ln=None):
     (>= 32768 rows), where the gate sits in the product's epilogue; the short node / global paths keep the gate inside
     l1's kernels (one launch fewer).
     ln = (gamma, beta, eps, drop_p, seed) of the residual LayerNorm that follows: where l2 can take it into its epilogue
-    (linear_ln_supported) the result is (LayerNorm(x + dropout(l2(.))), None) - the block is finished."""
+    (linear_ln_supported) the result is (LayerNorm(x + dropout(l2(.))), None) - the block is finished; the edge tensor's
+    block (ffn_ln_train_supported) runs as one forward kernel."""
     if handover is None:
         handover = x.numel() // x.shape[-1] >= 32768 and not option_set("NO_FFN_HANDOVER")
+    if ln is not None and handover and ffn_ln_train_supported(x, w1, w2):
+        gamma, beta, eps, p2, seed2 = ln
+        return _FfnLn.apply(x, w1, b1, w2, b2, gamma, beta, eps, drop_p, seed, p2, seed2), None
     scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
     h, xa = linear(x, w1, b1, act=1, drop_p=drop_p, seed=seed, with_alias=True, pregated=handover)
     if ln is not None and linear_ln_supported(h, w2, xa):

@@ -865,6 +865,61 @@ def test_ffn_gate_handover(ops, M, d, dff, default_routes):
         assert_close(a, b_, what=name + " hand-over vs in-layer gate")
 
 
+@pytest.mark.parametrize("M,p1,p2", [(8 * 64 * 64, 0.0, 0.0), (16 * 64 * 64, 0.1, 0.1), (32768 + 32 * 37, 0.25, 0.0), (40 * 32 * 32, 0.0, 0.1)])
+def test_edge_ffn_training_form_one_kernel(ops, M, p1, p2, default_routes):
+    """The edge tensor's feed-forward block in training (graph_transformer.py:139-142: linE1, ReLU, dropoutE2, linE2,
+    dropoutE3, residual, normE2) as ONE forward kernel that stores the hidden activation and the pre-LayerNorm sum for
+    the backward, and ONE backward kernel for both activation gradients (dh gated by the stored hidden activation, dx with
+    the residual branch's gradient): output and all seven gradients against plain torch without dropout; with dropout against the
+    two-kernel route on the same seeds (the keep-masks are hashed from the element position, so they are identical);
+    bitwise equal from run to run."""
+    g = torch.Generator().manual_seed(M)
+    # x, w1, b1 are small multiples of 1/8: every pre-activation is exact in fp32 in any summation order, so all routes
+    # and the CPU reference take the same side of every ReLU gate
+    x = torch.randint(-8, 9, (M, 64), generator=g).float() / 8
+    w1 = torch.randint(-8, 9, (128, 64), generator=g).float() / 8; b1 = torch.randint(-8, 9, (128,), generator=g).float() / 8
+    w2 = torch.randn(64, 128, generator=g) / math.sqrt(128); b2 = torch.randn(64, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(64, generator=g); beta = 0.1 * torch.randn(64, generator=g)
+    cot = torch.randn(M, 64, generator=g)
+    names = ("dx", "dw1", "db1", "dw2", "db2", "dgamma", "dbeta")
+
+    def run(one_kernel):
+        ins = [t.clone().cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2, gamma, beta)]
+        _lib.PROFILE = {}
+        try:
+            with _lib.option("NO_EDGE_FFN_TRAIN", 0 if one_kernel else 1):
+                y, xa = ops.ffn(*ins[:5], drop_p=p1, seed=777, ln=(ins[5], ins[6], 1e-5, p2, 4242))
+                assert xa is None
+                (y * cot.cuda()).sum().backward()
+                torch.cuda.synchronize()
+            called = {name for name, _ in _lib.PROFILE}
+        finally:
+            _lib.PROFILE = None
+        return y.detach(), [t.grad for t in ins], called
+
+    y, grads, called = run(True)
+    assert "mbvae_edge_ffn_fwd_train" in called and "mbvae_linear_ln_fwd" not in called and "mbvae_linear_fwd" not in called
+    assert {"mbvae_ln_sum_bwd", "mbvae_edge_ffn_bwd_data", "mbvae_linear_bwd_weight"} <= called
+    assert not {"mbvae_linear_bwd_input_outgate", "mbvae_linear_bwd_input_add", "mbvae_linear_bwd_input"} & called
+    if p1 == 0.0 and p2 == 0.0:
+        ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gamma, beta)]
+        yr = F.layer_norm(ref[0] + F.linear(F.relu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4]), (64,), ref[5], ref[6], 1e-5)
+        (yr * cot).sum().backward()
+        assert_close(y, yr, what="ffn + LayerNorm output")
+        for got, t, name in zip(grads, ref, names):
+            assert_close(got, t.grad, what=name)
+    y0, grads0, called0 = run(False)
+    assert not {"mbvae_edge_ffn_fwd_train", "mbvae_edge_ffn_bwd_data"} & called0
+    assert {"mbvae_linear_fwd", "mbvae_linear_ln_fwd", "mbvae_linear_bwd_input_outgate", "mbvae_linear_bwd_input_add"} <= called0
+    assert_close(y, y0, what="one kernel vs two")
+    if p1 > 0:                                          # the same hidden units were dropped: compare through db1's support
+        assert torch.equal(grads[2] == 0, grads0[2] == 0)
+    for a, b_, name in zip(grads, grads0, names):
+        assert_close(a, b_, what=name + ": one kernel vs two")
+    y2, grads2, _ = run(True)
+    assert torch.equal(y, y2) and all(torch.equal(a, b_) for a, b_ in zip(grads, grads2))
+
+
 @pytest.mark.parametrize("bs,n,K,masked,drop_p", [(16, 64, 256, True, 0.0), (16, 64, 128, False, 0.0), (2, 64, 256, True, 0.0),
                                                    (9, 64, 256, True, 0.1), (16, 32, 128, False, 0.1), (3, 64, 64, True, 0.25)])
 def test_linear_layernorm_epilogue(ops, bs, n, K, masked, drop_p, default_routes):
