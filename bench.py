@@ -270,7 +270,11 @@ def main():
                     "mbvae_edge_fused_fwd_recompute": s * (bs * n * n * (de + dx) + 4 * bs * n * dx),
                     "mbvae_edge_fused_bwd": s * (bs * n * n * (de + 3 * dx) + 10 * bs * n * dx),
                     # both gradients of the e_mul|e_add projection from one pass: dE1|dE2, E, addend in; dE out (+ weights)
-                    "mbvae_linear_bwd_both": s * (bs * n * n * (2 * dx + 3 * de) + 2 * (2 * dx * de))}
+                    "mbvae_linear_bwd_both": s * (bs * n * n * (2 * dx + 3 * de) + 2 * (2 * dx * de)),
+                    # edge feed-forward block, training pair: x in; hidden (2 de wide), pre-LayerNorm sum and output out /
+                    # dr, dres and the hidden activation in; dh and dx out
+                    "mbvae_edge_ffn_fwd_train": s * bs * n * n * (de + 2 * de + de + de),
+                    "mbvae_edge_ffn_bwd_data": s * bs * n * n * (de + de + 2 * de + 2 * de + de)}
         cands = []
         for (name, tag), evs in profile.items():
             ms = sum(a.elapsed_time(b) for a, b in evs)

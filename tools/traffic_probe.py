@@ -151,7 +151,27 @@ with torch.enable_grad():
     mark("mbvae_ln_sum_bwd:E")
     _ll.call("mbvae_ln_sum_bwd", *args_s)
     mark("setup")
-    del yl, zl, dxl, drl
+    del yl, zl
+    # the edge feed-forward block's training pair: one forward kernel, one backward kernel for both activation gradients
+    w1f = torch.randn(128, 64, device=dev) / 8; b1f = torch.zeros(128, device=dev)
+    w2f = torch.randn(64, 128, device=dev) / 11; b2f = torch.zeros(64, device=dev)
+    hf, zf, yf = torch.empty(M, 128, device=dev), torch.empty(M, 64, device=dev), torch.empty(M, 64, device=dev)
+    xf = x.detach().reshape(M, 64)
+    args_ff = (xf.data_ptr(), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(), g.data_ptr(), b.data_ptr(), hf.data_ptr(),
+               zf.data_ptr(), yf.data_ptr(), M, 64, 128, 1e-5, 0.1, 7, 0.1, 9, stl)
+    _ll.call("mbvae_edge_ffn_fwd_train", *args_ff)
+    torch.cuda.synchronize()
+    mark("mbvae_edge_ffn_fwd_train")
+    _ll.call("mbvae_edge_ffn_fwd_train", *args_ff)
+    mark("setup")
+    dhf = torch.empty(M, 128, device=dev)
+    args_fb = (drl.data_ptr(), dxl.data_ptr(), hf.data_ptr(), w1f.data_ptr(), w2f.data_ptr(), dhf.data_ptr(), yf.data_ptr(), M, 64, 128, 1.0 / 0.9, stl)
+    _ll.call("mbvae_edge_ffn_bwd_data", *args_fb)
+    torch.cuda.synchronize()
+    mark("mbvae_edge_ffn_bwd_data")
+    _ll.call("mbvae_edge_ffn_bwd_data", *args_fb)
+    mark("setup")
+    del hf, zf, yf, dhf, dxl, drl
     mark("mbvae_pool_stats_fwd:E")
     s = ops.pool_stats(x)
     # the backward entry point on its own, accumulating into an existing gradient as it does in the denoiser step
