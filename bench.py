@@ -121,7 +121,7 @@ def launch_workers(n, script=None, argv=None, have=None):
     script / argv / have: the worker program, its arguments and the number of visible GPUs (defaults: this file,
     this process' arguments, what torch counts) - parameters so that the launcher can be exercised without a GPU."""
     if have is None:
-        have = torch.cuda.device_count()        # counts devices without initialising the GPU runtime in this process
+        have = torch.cuda.device_count()        # (the only GPU-related call of this process; the children start fresh)
     if have < n:
         print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible", file=sys.stderr)
         return 2
