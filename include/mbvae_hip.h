@@ -33,12 +33,13 @@ typedef struct ihipStream_t* mbvae_stream_t; /* == hipStream_t */
 /* ---- tuning switches ------------------------------------------------------------------------------------
  * No counterpart in the reference.  Process-wide switches that choose between equivalent HIP routes (kernel A/B
  * timing, parity tests of the fallback kernels; never a CPU path).  Each starts from the environment variable
- * MBVAE_<NAME>, read once.  The 25 names (0 / 1 unless a range is given):
+ * MBVAE_<NAME>, read once.  The 26 names (0 / 1 unless a range is given):
  *   kernel families   NO_TSGEMM, NO_TSGEMM2 (tall-skinny products over the pair rows), TSGEMM_N64, NO_TSWGRAD, NO_TSWGRAD2
  *                     (their weight gradients), NO_SMALLM (few-tile products of the global-feature path), NO_COLGROUPS
  *                     (node-path column groups), NO_THIN (the 5-wide ends of the edge MLPs), GEMM_TILE (-1 automatic,
  *                     0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 32x128, 4 = 64x128 tiles of the generic kernel)
- *   arithmetic        NO_SPLIT_MFMA (edge-path products on the native fp32 matrix instructions instead of six bf16 ones)
+ *   arithmetic        NO_SPLIT_MFMA (all products on the native fp32 matrix instructions instead of six bf16 ones), NO_GEMM_SPLIT
+ *                     (the same choice for the generic LDS-tiled kernel only)
  *   attention block   NO_EDGE_FUSED, NO_EDGE_TRAIN_FUSED, NO_E12_RECOMPUTE (store e_mul|e_add instead of recomputing it in
  *                     the backward), NO_EF_COOP / NO_EFB_COOP (operand tile split per wave instead of once per
  *                     workgroup, forward / backward), EF_STAGGER (0..3: how the waves of a workgroup are phased),

@@ -50,6 +50,7 @@ enum MbvaeOption {
   MBVAE_OPT_NO_LN_EPILOGUE, // 64-wide edge Linears feeding a residual LayerNorm: separate Linear and LayerNorm kernels instead of the fused epilogue
   MBVAE_OPT_NO_THIN,        // Linear layers with <= 8 input or output features over the pair rows: the tiled kernels instead of the streaming ones
   MBVAE_OPT_NO_EDGE_FFN_TRAIN,   // training: the edge feed-forward block as two Linear kernels instead of the one-pass kernel (read by the host side too)
+  MBVAE_OPT_NO_GEMM_SPLIT,  // generic LDS-tiled kernel (node / global-feature / encoder Linears): native fp32 matrix instructions instead of the bf16 pipeline
   MBVAE_OPT_COUNT
 };
 inline const char* const* mbvae_option_names() {
@@ -57,7 +58,7 @@ inline const char* const* mbvae_option_names() {
                                                      "NO_EDGE_FUSED", "NO_EDGE_FFN", "NO_SMALLM", "NO_EDGE_TRAIN_FUSED",
                                                      "EA_KEYS", "NO_EA_PREFETCH", "GEMM_TILE", "NO_SPLIT_MFMA",
                                                      "NO_E12_RECOMPUTE", "EFB_SYNC", "EF_STAGGER", "NO_COLGROUPS", "NO_EF_COOP", "NO_EFB_COOP", "NO_FFN_HANDOVER", "NO_FILM", "NO_BWD_BOTH",
-                                                     "NO_LN_EPILOGUE", "NO_THIN", "NO_EDGE_FFN_TRAIN"};
+                                                     "NO_LN_EPILOGUE", "NO_THIN", "NO_EDGE_FFN_TRAIN", "NO_GEMM_SPLIT"};
   return names;
 }
 struct MbvaeOptions {

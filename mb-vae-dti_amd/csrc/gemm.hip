@@ -79,15 +79,23 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int r
 
 // FAST: every tile is full and 16-byte aligned (M % BM == 0, N % BN == 0, k range % 32 == 0, ld % 4 == 0), so the
 // staging loads are unconditional float4 loads with no bounds logic; GATE: the A prologue has a gate operand.
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool FAST, bool GATE>
+// SPLIT (with FAST): the products run on the bf16 matrix pipeline (six bf16 MFMAs per fp32 product, see mbvae_split8).
+// Every thread stages whole operand OCTETS - eight consecutive reduction indices of one row / column: two 16-byte loads
+// where the reduction index is contiguous in memory, eight coalesced 4-byte loads where it is the row index - splits them
+// once and parks the three bf16 planes in LDS, row-major with the reduction index contiguous (rows padded to 80 bytes:
+// the 16-byte operand fetches of the MFMA loop and the 16-byte stores of the staging are then spread over all banks).
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool FAST, bool GATE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int LDAS = A_KC ? BM + 1 : BM + 4;
   constexpr int LDBS = B_KC ? BN + 1 : BN + 4;
   constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // staged floats per thread
+  constexpr int KP = BK + 8;                               // SPLIT: bf16 elements per plane row
   static_assert(WM * WN == 4, "4 waves");
-  __shared__ __align__(16) float smem[BK * LDAS + BK * LDBS];
+  static_assert(!SPLIT || (FAST && BM % 64 == 0 && BN % 64 == 0), "the bf16-pipeline form takes whole aligned tiles");
+  __shared__ __align__(16) float smem[SPLIT ? 3 * (BM + BN) * KP / 2 : BK * LDAS + BK * LDBS];
+  __shared__ float csum4[SPLIT ? 4 * BM : 1];     // SPLIT: column-sum partials of the four octet groups
   __shared__ float keepM[BM];        // row-mask flags of the tile's M rows (epilogue mask, or A prologue when A_KC)
   __shared__ float keepK[2][BK];     // row-mask flags of the current k rows (A prologue when !A_KC), double-buffered
   float* As = smem;
@@ -154,6 +162,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   auto fetch = [&](int kt) {
     if (!A_KC && g.a_mask_mode != MBVAE_MASK_NONE && tid < BK)
       keepK[(kt >> 5) & 1][tid] = (kt + tid < kend) ? mbvae_row_keep(g.mask, g.a_mask_mode, kt + tid, g.n_nodes) : 0.f;
+    if (SPLIT) {
+      // octet (row / column, o): A_KC: row tid >> 2 (+ 64 p), octet tid & 3; else column tid & 63 (+ 64 p), octet tid >> 6
+#pragma unroll
+      for (int p = 0; p < BM / 64; ++p) {
+        if (A_KC) {
+          const int row = min(m0 + (tid >> 2) + 64 * p, g.M - 1);          // (a ragged last M tile re-reads row M-1)
+          const int64_t off = (int64_t)row * g.lda + kt + 8 * (tid & 3);
+          load4(g.A, true, off, true, 0, 4, &ra[p * 8]); load4(g.A, true, off + 4, true, 0, 4, &ra[p * 8 + 4]);
+          if (has_gate) { load4(g.a_gate, true, off, true, 0, 4, &rg[p * 8]); load4(g.a_gate, true, off + 4, true, 0, 4, &rg[p * 8 + 4]); }
+        } else {
+          const int64_t off = (int64_t)(kt + 8 * (tid >> 6)) * g.lda + m0 + (tid & 63) + 64 * p;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            ra[p * 8 + i] = g.A[off + (int64_t)i * g.lda];
+            if (has_gate) rg[p * 8 + i] = g.a_gate[off + (int64_t)i * g.lda];
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < BN / 64; ++p) {
+        if (B_KC) {
+          const int64_t off = (int64_t)(n0 + (tid >> 2) + 64 * p) * g.ldb + kt + 8 * (tid & 3);
+          load4(g.B, true, off, true, 0, 4, &rb[p * 8]); load4(g.B, true, off + 4, true, 0, 4, &rb[p * 8 + 4]);
+        } else {
+          const int64_t off = (int64_t)(kt + 8 * (tid >> 6)) * g.ldb + n0 + (tid & 63) + 64 * p;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) rb[p * 8 + i] = g.B[off + (int64_t)i * g.ldb];
+        }
+      }
+      return;
+    }
     if (A_KC) {
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
@@ -190,8 +229,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   };
 
   // kt = first reduction index of the tile held in the staging registers
+  float colsum_s[SPLIT ? BM / 64 : 1];             // SPLIT: this thread's share of the column sums (column tid & 63 + 64 p)
+#pragma unroll
+  for (int p = 0; p < (SPLIT ? BM / 64 : 1); ++p) colsum_s[p] = 0.f;
+  unsigned short* Ap = reinterpret_cast<unsigned short*>(smem);          // SPLIT: [3][BM][KP]
+  unsigned short* Bp = Ap + 3 * BM * KP;                                   //        [3][BN][KP]
   auto commit = [&](int kt) {
     const bool prologue = has_gate || g.a_mask_mode != MBVAE_MASK_NONE || g.a_gate_scale != 1.f;
+    if (SPLIT) {
+#pragma unroll
+      for (int p = 0; p < BM / 64; ++p) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = ra[p * 8 + i];
+          if (has_gate && !(rg[p * 8 + i] > 0.f)) v[i] = 0.f;
+          if (prologue) {
+            float keep = g.a_gate_scale;
+            if (g.a_mask_mode != MBVAE_MASK_NONE)
+              keep *= A_KC ? keepM[(tid >> 2) + 64 * p] : keepK[(kt >> 5) & 1][8 * (tid >> 6) + i];
+            v[i] = keep != 0.f ? v[i] * keep : 0.f;      // select: masked rows may hold non-finite values
+          }
+        }
+        if (!A_KC) colsum_s[p] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const MbvaeSplit3 sp = mbvae_split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        unsigned short* dst = A_KC ? Ap + ((tid >> 2) + 64 * p) * KP + 8 * (tid & 3) : Ap + ((tid & 63) + 64 * p) * KP + 8 * (tid >> 6);
+        *reinterpret_cast<mbvae_bf16x8*>(dst) = sp.hi;
+        *reinterpret_cast<mbvae_bf16x8*>(dst + BM * KP) = sp.mid;
+        *reinterpret_cast<mbvae_bf16x8*>(dst + 2 * BM * KP) = sp.lo;
+      }
+#pragma unroll
+      for (int p = 0; p < BN / 64; ++p) {
+        const MbvaeSplit3 sp = mbvae_split8(rb[p * 8], rb[p * 8 + 1], rb[p * 8 + 2], rb[p * 8 + 3], rb[p * 8 + 4], rb[p * 8 + 5],
+                                            rb[p * 8 + 6], rb[p * 8 + 7]);
+        unsigned short* dst = B_KC ? Bp + ((tid >> 2) + 64 * p) * KP + 8 * (tid & 3) : Bp + ((tid & 63) + 64 * p) * KP + 8 * (tid >> 6);
+        *reinterpret_cast<mbvae_bf16x8*>(dst) = sp.hi;
+        *reinterpret_cast<mbvae_bf16x8*>(dst + BN * KP) = sp.mid;
+        *reinterpret_cast<mbvae_bf16x8*>(dst + 2 * BN * KP) = sp.lo;
+      }
+      return;
+    }
     if (A_KC) {
 #pragma unroll
       for (int p = 0; p < BM / 32; ++p) {
@@ -247,6 +324,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     commit(kt);
     __syncthreads();
     fetch(min(kt + BK, klast));
+    if (SPLIT) {
+#pragma unroll
+      for (int st = 0; st < BK / 16; ++st) {
+        mbvae_bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned short* ap = Ap + ((wm * TM + i) * 32 + r) * KP + 16 * st + 8 * h;
+          ah[i] = *reinterpret_cast<const mbvae_bf16x8*>(ap);
+          am[i] = *reinterpret_cast<const mbvae_bf16x8*>(ap + BM * KP);
+          al[i] = *reinterpret_cast<const mbvae_bf16x8*>(ap + 2 * BM * KP);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const unsigned short* bp = Bp + ((wn * TN + j) * 32 + r) * KP + 16 * st + 8 * h;
+          bh[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp);
+          bm[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + BN * KP);
+          bl[j] = *reinterpret_cast<const mbvae_bf16x8*>(bp + 2 * BN * KP);
+        }
+        // smaller terms first
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(am[i], bm[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(am[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(ah[i], bm[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MBVAE_MFMA_BF16(ah[i], bh[j], acc[i][j]);
+      }
+      continue;
+    }
     if (want_colsum && tid < BM) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) colsum += As[k * LDAS + tid];
@@ -266,6 +389,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
   }
 
+  if (SPLIT && want_colsum) {                        // the four octet groups' shares of the column sums meet in LDS, in order
+#pragma unroll
+    for (int p = 0; p < BM / 64; ++p) csum4[(tid >> 6) * BM + (tid & 63) + 64 * p] = colsum_s[p];
+    __syncthreads();
+    if (tid < BM) colsum = ((csum4[tid] + csum4[BM + tid]) + csum4[2 * BM + tid]) + csum4[3 * BM + tid];
+  }
   // ---- write back.  C/D layout of the 32x32 tile: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5).
   // Bias values and row-mask flags are fetched up front: loads issued between the stores would each be waited
   // for (the stores may alias them as far as the compiler knows) and serialise the epilogue on L2 latency.
@@ -2171,18 +2300,27 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   // branch-free operand loads: whole N and K tiles; M may be ragged when A is [M,K] (rows are clamped, see fetch)
   const bool fast = aligned && (A_KC || g.M % BM == 0) && g.N % BN == 0 && g.K % 32 == 0;
   const bool gate = g.a_gate != nullptr;
-#define GEMM_LAUNCH(bm, bn, wm, wn)                                                                                     \
+  // whole aligned tiles run on the bf16 matrix pipeline (fp32-exact three-way operand splits, planes staged in LDS)
+  const bool split = fast && !mbvae_opt(MBVAE_OPT_NO_SPLIT_MFMA) && !mbvae_opt(MBVAE_OPT_NO_GEMM_SPLIT);
+#define GEMM_LAUNCH_F32(bm, bn, wm, wn)                                                                                 \
   do {                                                                                                                   \
     if (fast && gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, true>), grid, block, 0, stream, g);        \
     else if (fast) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, false>), grid, block, 0, stream, g);          \
     else if (gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, true>), grid, block, 0, stream, g);          \
     else hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, false, false>), grid, block, 0, stream, g);                   \
   } while (0)
-  if (BM == 32) GEMM_LAUNCH(32, 128, 1, 4);
+#define GEMM_LAUNCH(bm, bn, wm, wn)                                                                                     \
+  do {                                                                                                                   \
+    if (split && gate) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, true, true>), grid, block, 0, stream, g); \
+    else if (split) hipLaunchKernelGGL((gemm_f32_kernel<bm, bn, wm, wn, A_KC, B_KC, true, false, true>), grid, block, 0, stream, g);   \
+    else GEMM_LAUNCH_F32(bm, bn, wm, wn);                                                                                \
+  } while (0)
+  if (BM == 32) GEMM_LAUNCH_F32(32, 128, 1, 4);
   else if (BM == 64 && BN == 128) GEMM_LAUNCH(64, 128, 2, 2);
   else if (BM == 64) GEMM_LAUNCH(64, 64, 2, 2);
   else if (BN == 64) GEMM_LAUNCH(128, 64, 4, 1);
   else GEMM_LAUNCH(128, 128, 2, 2);
+#undef GEMM_LAUNCH_F32
 #undef GEMM_LAUNCH
   if (splits > 1) {
     const int64_t total = (int64_t)g.M * g.N + g.M;
