@@ -54,9 +54,10 @@ int mbvae_set_option(const char* name, int value);
 int mbvae_get_option(const char* name);
 
 /* ---- Linear layers on the matrix cores ------------------------------------------------------------------
- * fp32 in, fp32 out, fp32 accumulation.  Products over the pair rows ([bs*n*n, d] shapes) run on the bf16 matrix
- * instructions with every fp32 operand cut exactly into three bf16 words (six products per fp32 product, error as the
- * native fp32 instruction's); all other shapes run on the native fp32 matrix instruction.
+ * fp32 in, fp32 out, fp32 accumulation.  Products over the pair rows ([bs*n*n, d] shapes) and all other shapes made of
+ * whole aligned tiles run on the bf16 matrix instructions with every fp32 operand cut exactly into three bf16 words (six
+ * products per fp32 product, error as the native fp32 instruction's); ragged or unaligned shapes and the few-tile
+ * products of the global-feature path run on the native fp32 matrix instruction.
  * Replaces nn.Linear forward/backward plus the `* x_mask`, `* e_mask1 * e_mask2`, ReLU and Dropout that
  * surround it in mb_vae_dti/training/models/graph_transformer.py:201-202,217-221,233,240,257 (NodeEdgeBlock),
  * :134-144 (feed-forward blocks), :283-308,321-335 (in/out MLPs) and the encoder / head MLPs of
