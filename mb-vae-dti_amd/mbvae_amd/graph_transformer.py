@@ -53,6 +53,50 @@ class Etoy(nn.Module):
         return _lin(self.lin, ops.pool_stats(E))
 
 
+_NO_STACK_CACHE = os.environ.get("MBVAE_NO_STACK_CACHE", "0") not in ("", "0")
+
+
+class _StackedParams(torch.autograd.Function):
+    """(stacked weight, stacked bias) of several Linear layers as a function of their parameters: the forward hands out the
+    up-to-date copies it is given (no kernel), the backward returns row slices of the stacked gradients."""
+
+    @staticmethod
+    def forward(ctx, w, b, *params):
+        ctx.rows = [p.shape[0] for p in params[0::2]]
+        return w.view_as(w), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, dw, db):
+        out = [None, None]
+        r0 = 0
+        for i, rows in enumerate(ctx.rows):
+            out.append(dw[r0:r0 + rows] if (dw is not None and ctx.needs_input_grad[2 + 2 * i]) else None)
+            out.append(db[r0:r0 + rows] if (db is not None and ctx.needs_input_grad[3 + 2 * i]) else None)
+            r0 += rows
+        return tuple(out)
+
+
+def refresh_stacked_weights(model):
+    """Renews every stacked weight / bias copy of the model's attention blocks from the layers' parameters, all of them in
+    one multi-tensor copy (call it on the stream that ran the optimiser step, right after it).  Blocks whose copies do
+    not exist yet are left to build them at their next forward."""
+    dst, src, hits = [], [], []
+    for m in model.modules():
+        cache = m.__dict__.get("_stack_cache") if isinstance(m, NodeEdgeBlock) else None
+        for hit in (cache or {}).values():
+            r0 = 0
+            for l in hit[3]:
+                rows = l.weight.shape[0]
+                dst += [hit[1][r0:r0 + rows], hit[2][r0:r0 + rows]]; src += [l.weight, l.bias]
+                r0 += rows
+            hits.append(hit)
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, [p.detach() for p in src])
+        for hit in hits:
+            hit[0] = tuple((p.data_ptr(), p._version) for l in hit[3] for p in (l.weight, l.bias))
+
+
 class NodeEdgeBlock(nn.Module):
     """Self-attention block that also updates the edge and global representations."""
 
@@ -70,18 +114,27 @@ class NodeEdgeBlock(nn.Module):
         self.y_out = nn.Sequential(nn.Linear(dy, dy), nn.ReLU(), nn.Linear(dy, dy))
 
     def _stacked(self, key, layers):
-        """Weights and biases of several Linear layers side by side.  With gradients they are rebuilt from the layers'
-        own parameters every call (autograd splits the gradient); without, the copy is kept until a parameter changes
-        (in-place updates and load_state_dict bump the tensors' version counters; .data swaps change data_ptr)."""
-        if torch.is_grad_enabled():
+        """Weights and biases of several Linear layers side by side.  The copy is kept until a parameter changes
+        (in-place updates and load_state_dict bump the tensors' version counters; .data swaps change data_ptr).  With
+        gradients it enters autograd through _StackedParams, whose backward hands each layer its slice of the stacked
+        gradient; refresh_stacked_weights() renews all copies of a model in a few launches after an optimiser step, so
+        that no concatenation sits in front of the products."""
+        if _NO_STACK_CACHE and torch.is_grad_enabled():      # A/B aid: concatenate at every call, as autograd nodes
             return torch.cat([l.weight for l in layers], 0), torch.cat([l.bias for l in layers], 0)
-        stamp = tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight, l.bias))
+        params = [p for l in layers for p in (l.weight, l.bias)]
+        stamp = tuple((p.data_ptr(), p._version) for p in params)
         cache = self.__dict__.setdefault("_stack_cache", {})
         hit = cache.get(key)
         if hit is None or hit[0] != stamp:
             with torch.no_grad():
-                hit = (stamp, torch.cat([l.weight for l in layers], 0), torch.cat([l.bias for l in layers], 0))
+                if hit is None:
+                    hit = [stamp, torch.cat([l.weight for l in layers], 0), torch.cat([l.bias for l in layers], 0), layers]
+                else:                       # renew in place: the buffers may be referenced by a refresh list
+                    torch.cat([l.weight for l in layers], 0, out=hit[1]); torch.cat([l.bias for l in layers], 0, out=hit[2])
+                    hit[0] = stamp
             cache[key] = hit
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _StackedParams.apply(hit[1], hit[2], *params)
         return hit[1], hit[2]
 
     def _fused(self, key, x, layers, **kw):

@@ -12,7 +12,7 @@ from . import ops
 from .ddp import BucketedGradSync
 from .diffusion import PredefinedNoiseScheduleDiscrete, exp_draws
 from .features import ExtraFeatures, ExtraMolecularFeatures
-from .graph_transformer import GraphTransformer
+from .graph_transformer import GraphTransformer, refresh_stacked_weights
 
 CFG3 = dict(  # the benchmark denoiser: 8 layers, 5 atom / 5 bond classes, reference widths
     n_layers=8, input_dims={"X": 13, "E": 5, "y": 1037}, output_dims={"X": 5, "E": 5, "y": 1024},
@@ -109,6 +109,7 @@ class DenoiserTrainStep:
         side = ops.side_stream(dev) if self.sync is None else None
         if side is None:
             self.opt.step()
+            refresh_stacked_weights(self.model)
         else:
             # The optimiser's sweep over the weights (memory bound) on the second stream: the next step's noising and
             # graph features (latency bound, no weights involved) start next to it; the denoiser waits for it below.
@@ -119,6 +120,7 @@ class DenoiserTrainStep:
                     p.grad.record_stream(side)       # (freed right after this call; the allocator must wait for the sweep)
             with torch.cuda.stream(side):
                 self.opt.step()
+                refresh_stacked_weights(self.model)      # (the next forward then finds its stacked projections ready)
             self._opt_pending = side
             if not self.overlap_optimizer:
                 self.wait_optimizer()
