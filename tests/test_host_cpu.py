@@ -324,3 +324,38 @@ def test_bench_launcher_passes_on_the_worst_exit_status_and_refuses_missing_gpus
     sub.mkdir()
     r, seen = _run_launcher(sub, 4, have=2)
     assert r.returncode == 2 and not seen and "4 requested but 2" in r.stderr.replace("--gpus ", "")
+
+
+def test_stacked_projection_weights_follow_their_parameters():
+    """The stacked q|k|v weights are kept as a copy: it must follow every way a parameter can change (optimiser-style
+    in-place update, load_state_dict, a swapped .data), refresh_stacked_weights must renew it in one go, and gradients must
+    reach the layers' own parameters through it."""
+    sys.path.insert(0, os.path.join(ROOT, "mb-vae-dti_amd"))
+    from mbvae_amd.graph_transformer import NodeEdgeBlock, refresh_stacked_weights
+    torch.manual_seed(0)
+    blk = NodeEdgeBlock(8, 4, 8, 2)
+    layers = (blk.q, blk.k, blk.v)
+    want = lambda: (torch.cat([l.weight for l in layers], 0).detach(), torch.cat([l.bias for l in layers], 0).detach())
+    w, b = blk._stacked("qkv", layers)
+    assert torch.equal(w, want()[0]) and torch.equal(b, want()[1]) and w.requires_grad
+    (w.sum() + 2 * b.sum()).backward()
+    for l in layers:
+        assert torch.equal(l.weight.grad, torch.ones_like(l.weight)) and torch.equal(l.bias.grad, torch.full_like(l.bias, 2.0))
+    buf = blk._stack_cache["qkv"][1]
+    with torch.no_grad():
+        blk.k.weight.add_(1.0)                                   # in-place update: version counter
+    w, b = blk._stacked("qkv", layers)
+    assert torch.equal(w, want()[0]) and blk._stack_cache["qkv"][1] is buf      # renewed in place
+    blk.load_state_dict({k: v + 0.5 for k, v in blk.state_dict().items()})
+    assert torch.equal(blk._stacked("qkv", layers)[0], want()[0])
+    blk.v.bias.data = torch.full_like(blk.v.bias, 3.0)           # swapped storage: data_ptr
+    assert torch.equal(blk._stacked("qkv", layers)[1], want()[1])
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.mul_(0.9)
+    refresh_stacked_weights(blk)                                 # all copies of the model at once
+    hit = blk._stack_cache["qkv"]
+    assert torch.equal(hit[1], want()[0]) and torch.equal(hit[2], want()[1])
+    assert hit[0] == tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight, l.bias))
+    with torch.no_grad():
+        assert not blk._stacked("qkv", layers)[0].requires_grad
