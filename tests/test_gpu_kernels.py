@@ -97,6 +97,45 @@ def test_linear_fwd_bwd(ops, M, K, N, act, mode):
     assert_close(bg.grad, br.grad, what="db")
 
 
+@pytest.mark.parametrize("M,K,N,act,mode", [
+    (16384, 256, 256, 1, "node"), (16384, 256, 256, 0, "none"), (8192, 256, 768, 0, "node"), (4096, 128, 192, 1, "none"),
+    (512, 1024, 1024, 1, "none"), (1024, 2048, 128, 0, "none"), (640, 96, 64, 0, "node"),
+])
+def test_generic_gemm_on_the_bf16_pipeline_matches_the_fp32_route(ops, M, K, N, act, mode):
+    """Whole aligned tiles of the generic LDS-tiled kernel run on the bf16 matrix pipeline (operand octets split once,
+    three planes in LDS); NO_GEMM_SPLIT keeps them on the fp32 matrix instruction.  Forward, input, weight and bias
+    gradients (the weight gradient's reduction runs over the rows and is split over workgroups; the bias gradient comes
+    from the staged octets' column sums) of both routes against float64, 1e-5 of each tensor's scale; run twice: same bits."""
+    from mbvae_amd import _lib
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g) * 0.1
+    cot = torch.randn(M, N, generator=g)
+    mask, n, mm, keep = None, 0, ops.MASK_NONE, torch.ones(M, 1)
+    if mode == "node":
+        n = 64; mask = ragged_mask(M // n, n, g); mm = ops.MASK_NODE; keep = mask.reshape(M, 1).float()
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = F.linear(xr, wr, br)
+    if act:
+        cot = cot * (y.detach().abs() > 1e-5)            # (a pre-activation within rounding of zero: either side is right)
+    y = (F.relu(y) if act else y) * keep.double()
+    (y * cot.double()).sum().backward()
+
+    def run(no_split):
+        with _lib.option("NO_GEMM_SPLIT", no_split), _lib.option("NO_TSGEMM", 1), _lib.option("NO_SMALLM", 1):
+            xg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            yg = ops.linear(xg, wg, bg, act=act, mask=dev(mask), mask_mode=mm, n_nodes=n)
+            (yg * cot.cuda()).sum().backward()
+            torch.cuda.synchronize()
+        return yg.detach(), xg.grad, wg.grad, bg.grad
+
+    for no_split in (0, 1):
+        got = run(no_split)
+        for a, r, name in zip(got, (y, xr.grad, wr.grad, br.grad), ("y", "dx", "dw", "db")):
+            assert_close(a, r, what=f"{name} (NO_GEMM_SPLIT={no_split})")
+        again = run(no_split)
+        assert all(torch.equal(a, b_) for a, b_ in zip(got, again))
+
+
 def test_linear_relu_dropout_statistics(ops):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(4096, 64, generator=g).cuda().requires_grad_(True)
