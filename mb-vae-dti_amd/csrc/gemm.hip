@@ -2277,7 +2277,7 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   }
   int BM, BN;
   if (g.M <= 64 || g.N <= 32 || (int64_t)g.M * g.N <= 512 * 1024) { BM = 64; BN = 64; }
-  else if (g.N <= 64) { BM = 128; BN = 64; }
+  else if (g.N <= 256) { BM = 128; BN = 64; }     // (256-wide node layers over packed rows: 2.5 % faster sampling step than 128x128)
   else { BM = 128; BN = 128; }
   // fewer than two big tiles per CU leave the chip under-filled and every block latency bound: use small tiles
   if (BM == 128 && (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) < 2 * ts_num_cus()) { BM = 64; BN = 64; }
