@@ -1,6 +1,8 @@
 # Profiles of one round (GPU box): kernel traces of the bench and of the sampling loop, and three counter passes over tools/traffic_probe.py
 # (HBM reads, HBM writes, matrix-core / vector-unit busy cycles).  usage: bash tools/profile_round.sh <tag>
 set -e
+# (gpurun MERGES what a call wrote into the local gpurun_out/: remove the local copy of prof_<tag> before a re-run, or
+#  tools/pmc_summary.py may pick up an older pass's counter file)
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
