@@ -126,6 +126,17 @@ int mbvae_film_fwd(const float* add, const float* mul, const float* x, float* ou
 int mbvae_film_bwd(const float* dout, const float* mul, const float* x, float* dx, float* dadd, float* dmul, int64_t bs,
                    int64_t n, int64_t D, mbvae_stream_t stream);
 
+/* Sigmoid-gate update of the feature encoders and of the drug / target fusion (models/blocks.py:125 `x + x * att(x)`,
+ * :318 `a + gate_a * align_proj(b)`, :321-322): y = x + u * g with g = sigmoid(z) * keep * scale, element-wise over n
+ * floats; z is the output of the gate's second Linear, keep the dropout keep mask of the gate (nn.Dropout after the
+ * Sigmoid, :92-99: one byte per element, NULL = no dropout, scale = 1 / (1 - p)), u may be x itself.
+ * Backward: g is recomputed from z and keep; du = dy * g, or with u_is_x the whole gradient of x, dy + dy * g;
+ * dz = dy * u * keep * scale * s * (1 - s), s = sigmoid(z).  The gradient of x in the other case is dy itself. */
+int mbvae_gate_fwd(const float* x, const float* u, const float* z, const uint8_t* keep, float scale, float* y, int64_t n,
+                   mbvae_stream_t stream);
+int mbvae_gate_bwd(const float* dy, const float* u, const float* z, const uint8_t* keep, float scale, float* du, float* dz,
+                   int64_t n, int u_is_x, mbvae_stream_t stream);
+
 /* ---- Edge-feature attention ------------------------------------------------------------------------
  * Replaces graph_transformer.py:206-249 (Y = Q*K/sqrt(df); Y*(E1+1)+E2; FiLM by y; per-channel masked
  * softmax over keys, masked_softmax :22-27; weighted V).  Q,K,V [bs,n,dx] with rows ldq floats apart and

@@ -658,6 +658,33 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sigmoid-gate update of the encoders:  y = x + u * g,  g = sigmoid(z) * keep * scale   (all [n] element-wise; keep is the
+// dropout keep mask of the gate, one byte per element, null = no dropout).  Backward from (dy, u, z, keep): g recomputed;
+// du = dy * g (or, where u IS x, dx = dy + dy * g in one tensor), dz = dy * u * keep * scale * s * (1 - s).
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                       const float* __restrict__ z, const uint8_t* __restrict__ keep, float scale,
+                                                       float* __restrict__ y, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float s = 1.f / (1.f + expf(-z[e]));
+    const float g = keep ? (keep[e] ? s * scale : 0.f) : s;
+    y[e] = x[e] + u[e] * g;
+  }
+}
+
+template <bool U_IS_X>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ u,
+                                                       const float* __restrict__ z, const uint8_t* __restrict__ keep, float scale,
+                                                       float* __restrict__ du, float* __restrict__ dz, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float s = 1.f / (1.f + expf(-z[e]));
+    const float k = keep ? (keep[e] ? scale : 0.f) : 1.f;
+    const float g = dy[e];
+    du[e] = U_IS_X ? g + g * (s * k) : g * (s * k);
+    dz[e] = g * u[e] * k * (s * (1.f - s));
+  }
+}
+
 extern "C" {
 
 // y = LayerNorm(x + dropout_p(r)) * gamma + beta over the last dim D; r may be null.  Saves mean/rstd [rows].
@@ -883,6 +910,27 @@ int mbvae_film_bwd(const float* dout, const float* mul, const float* x, float* d
   if (!dout || !mul || !x || !dx || !dadd || !dmul || bs <= 0 || n <= 0 || D <= 0) return MBVAE_EINVAL;
   if (bs > 0x7fffffff || n > 0x7fffffff || D > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   hipLaunchKernelGGL(film_bwd_kernel, dim3((unsigned)bs), dim3(256), 0, stream, dout, mul, x, dx, dadd, dmul, (int)n, (int)D);
+  return mbvae_launch_status();
+}
+
+// y = x + u * sigmoid(z) * keep * scale, element-wise over n floats (u may be x itself; keep null: no dropout)
+int mbvae_gate_fwd(const float* x, const float* u, const float* z, const uint8_t* keep, float scale, float* y, int64_t n,
+                   hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !u || !z || !y || n <= 0) return MBVAE_EINVAL;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, x, u, z, keep,
+                     scale, y, n);
+  return mbvae_launch_status();
+}
+
+// du = dy * g (u_is_x: dy + dy * g, the whole gradient of x), dz = dy * u * keep * scale * s * (1 - s); g, s from z and keep
+int mbvae_gate_bwd(const float* dy, const float* u, const float* z, const uint8_t* keep, float scale, float* du, float* dz,
+                   int64_t n, int u_is_x, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !u || !z || !du || !dz || n <= 0) return MBVAE_EINVAL;
+  const dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 8192));
+  if (u_is_x) hipLaunchKernelGGL(gate_bwd_kernel<true>, grid, dim3(256), 0, stream, dy, u, z, keep, scale, du, dz, n);
+  else hipLaunchKernelGGL(gate_bwd_kernel<false>, grid, dim3(256), 0, stream, dy, u, z, keep, scale, du, dz, n);
   return mbvae_launch_status();
 }
 

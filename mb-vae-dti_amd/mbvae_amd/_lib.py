@@ -28,6 +28,8 @@ SIGNATURES = {
     "mbvae_linear_bwd_input_outgate": [_P, _L, _P, _P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _P, _L, _P],
     "mbvae_film_fwd": [_P, _P, _P, _P, _L, _L, _L, _P],
     "mbvae_film_bwd": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    "mbvae_gate_fwd": [_P, _P, _P, _P, _F, _P, _L, _P],
+    "mbvae_gate_bwd": [_P, _P, _P, _P, _F, _P, _P, _L, _I, _P],
     "mbvae_linear_bwd_both": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _L, _L, _L, _P, _I, _I, _P, _L, _P],
     "mbvae_edge_attn_fwd": [_P, _P, _P, _L, _P, _P, _L] + [_P] * 6 + [_L, _L, _L, _F, _P],
     "mbvae_edge_attn_bwd_workspace": [_L, _L, _L],

@@ -39,10 +39,11 @@ def _mlp_block(seq, x, activation, training):
     return _lin(seq[4], _drop(h, seq[3].p, training))
 
 
-def _gate_block(seq, x, activation, training):
-    """LayerNorm -> Linear -> act -> Linear -> Sigmoid -> Dropout   (indices 0..5)."""
-    g = torch.sigmoid(_lin(seq[3], _act_linear(seq[1], _ln(seq[0], x), activation)))
-    return _drop(g, seq[5].p, training)
+def _gated(seq, x, u, gate_in, activation, training):
+    """x + u * gate(gate_in), gate = LayerNorm -> Linear -> act -> Linear -> Sigmoid -> Dropout (indices 0..5 of the
+    Sequential); u None: x + x * gate.  Sigmoid, dropout, product and sum run as one kernel (ops.gate_update)."""
+    z = _lin(seq[3], _act_linear(seq[1], _ln(seq[0], gate_in), activation))
+    return ops.gate_update(x, u, z, seq[5].p, training)
 
 
 class ResidualEncoder(nn.Module):
@@ -85,7 +86,7 @@ class TransformerEncoder(nn.Module):
     def forward(self, x):
         x = _lin(self.input_proj, x)
         for att, mlp in zip(self.att_layers, self.mlp_layers):
-            x = x + x * _gate_block(att, x, self.activation, self.training)
+            x = _gated(att, x, None, x, self.activation, self.training)
             x = x + _mlp_block(mlp, x, self.activation, self.training)
         return _lin(self.output_proj[1], _ln(self.output_proj[0], x))
 
@@ -156,11 +157,10 @@ class CrossAttentionFusion(nn.Module):
     def forward(self, a, b):
         act, tr = self.activation, self.training
         for i in range(self.n_layers):
-            ga = _gate_block(self.cross_gates_b_to_a[i], torch.cat([a, b], dim=-1), act, tr)
-            gb = _gate_block(self.cross_gates_a_to_b[i], torch.cat([b, a], dim=-1), act, tr)
-            a, b = a + ga * _lin(self.align_proj_b_to_a[i], b), b + gb * _lin(self.align_proj_a_to_b[i], a)
-            a = a + a * _gate_block(self.self_gates_a[i], a, act, tr)
-            b = b + b * _gate_block(self.self_gates_b[i], b, act, tr)
+            a, b = (_gated(self.cross_gates_b_to_a[i], a, _lin(self.align_proj_b_to_a[i], b), torch.cat([a, b], dim=-1), act, tr),
+                    _gated(self.cross_gates_a_to_b[i], b, _lin(self.align_proj_a_to_b[i], a), torch.cat([b, a], dim=-1), act, tr))
+            a = _gated(self.self_gates_a[i], a, None, a, act, tr)
+            b = _gated(self.self_gates_b[i], b, None, b, act, tr)
             a = a + _mlp_block(self.mlp_a[i], a, act, tr)
             b = b + _mlp_block(self.mlp_b[i], b, act, tr)
         return self.att_agg([a, b])

@@ -316,6 +316,47 @@ def ffn(x, w1, b1, w2, b2, drop_p=0.0, seed=0, handover=None, ln=None):
     return linear(h, w2, b2, in_gate_scale=scale if handover else None), xa
 
 
+# ------------------------------------------------------------------------------------------------ sigmoid-gate update
+class _GateUpdate(torch.autograd.Function):
+    """y = x + u * (sigmoid(z) * keep * scale) in one kernel each way (u None: u is x).  The gate is recomputed from z and the
+    keep mask in the backward, nothing else is stored."""
+
+    @staticmethod
+    def forward(ctx, x, u, z, keep, scale):
+        x, z = _f32c(x, "x"), _f32c(z, "z")
+        uu = x if u is None else _f32c(u, "u")
+        if uu.shape != x.shape or z.shape != x.shape or (keep is not None and (keep.shape != x.shape or keep.dtype != torch.uint8
+                                                                                 or not keep.is_contiguous())):
+            raise ValueError("gate update: x, u, z and the keep mask (uint8, contiguous) must have one shape")
+        y = torch.empty_like(x)
+        _lib.call("mbvae_gate_fwd", x.data_ptr(), uu.data_ptr(), z.data_ptr(), _ptr(keep), float(scale), y.data_ptr(), x.numel(),
+                  _stream())
+        ctx.save_for_backward(uu, z, keep)
+        ctx.cfg = (float(scale), u is None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        uu, z, keep = ctx.saved_tensors
+        scale, u_is_x = ctx.cfg
+        dy = _f32c(dy, "dy")
+        du, dz = torch.empty_like(uu), torch.empty_like(z)
+        _lib.call("mbvae_gate_bwd", dy.data_ptr(), uu.data_ptr(), z.data_ptr(), _ptr(keep), scale, du.data_ptr(), dz.data_ptr(),
+                  uu.numel(), int(u_is_x), _stream())
+        return (du, None, dz, None, None) if u_is_x else (dy, du, dz, None, None)
+
+
+def gate_update(x, u, z, drop_p=0.0, training=False):
+    """x + u * dropout(sigmoid(z)) (u None: x + x * dropout(sigmoid(z))): the gated residual updates of TransformerEncoder and
+    CrossAttentionFusion (mb_vae_dti/training/models/blocks.py:125, :318-322).  The keep mask is drawn by torch's generator
+    (one byte per element), so a captured HIP graph draws fresh masks on every replay."""
+    keep, scale = None, 1.0
+    if training and drop_p > 0:
+        keep = torch.empty(z.shape, dtype=torch.uint8, device=z.device).bernoulli_(1.0 - drop_p)
+        scale = 1.0 / (1.0 - drop_p)
+    return _GateUpdate.apply(x, u, z, keep, scale)
+
+
 # ------------------------------------------------------------------------------------------------ edge-tensor fan-out
 class _EdgeInput(torch.autograd.Function):
     """The three consumers of a layer's edge tensor E in one autograd node: the fused e_mul|e_add projection, the

@@ -861,6 +861,46 @@ def test_film(ops, bs, n, D):
     assert torch.equal(y, y2) and all(torch.equal(a, b_) for a, b_ in zip(grads, grads2))
 
 
+@pytest.mark.parametrize("shape,own,drop", [((256, 512), True, True), ((256, 1024), False, True), ((37, 24), True, False),
+                                            ((5, 3, 7), False, False)])
+def test_gate_update(ops, shape, own, drop):
+    """x + u * dropout(sigmoid(z)) as one kernel each way (models/blocks.py:125, :318-322): values and every gradient against
+    the torch expression in float64 with the same keep mask; u = x (self gate) and a separate u (cross gate); bitwise equal
+    from run to run; in training mode the op draws a mask that keeps about 1 - p of the entries and scales them."""
+    from mbvae_amd.ops import _GateUpdate
+    g = torch.Generator().manual_seed(sum(shape))
+    x, u, z, c = (torch.randn(*shape, generator=g) for _ in range(4))
+    keep = (torch.rand(*shape, generator=g) < 0.9).to(torch.uint8) if drop else None
+    scale = 1 / 0.9 if drop else 1.0
+    ref = [t.double().requires_grad_(True) for t in (x, u, z)]
+    gate = torch.sigmoid(ref[2]) * (keep.double() * scale if drop else 1.0)
+    yr = ref[0] + (ref[0] if own else ref[1]) * gate
+    (yr * c.double()).sum().backward()
+
+    def run():
+        ins = [t.clone().cuda().requires_grad_(True) for t in (x, u, z)]
+        y = _GateUpdate.apply(ins[0], None if own else ins[1], ins[2], keep.cuda() if drop else None, scale)
+        (y * c.cuda()).sum().backward()
+        return y.detach(), [t.grad for t in ins]
+
+    y, grads = run()
+    assert_close(y, yr.float(), what="gate update")
+    for got, t, name in zip(grads, ref, ("dx", "du", "dz")):
+        if name == "du" and own:
+            assert got is None
+        else:
+            assert_close(got, t.grad.float(), what=name)
+    y2, grads2 = run()
+    assert torch.equal(y, y2) and all(a is b_ or torch.equal(a, b_) for a, b_ in zip(grads, grads2))
+    if drop:
+        xs = torch.ones(*shape).cuda(); zs = torch.full(shape, 20.0).cuda()          # sigmoid(20) = 1 in fp32
+        torch.manual_seed(3)
+        kept = ops.gate_update(xs, None, zs, 0.25, training=True) - 1
+        frac = float((kept > 0).float().mean())
+        assert abs(frac - 0.75) < 0.01 and torch.all((kept == 0) | ((kept - 1 / 0.75).abs() < 1e-6))
+        assert torch.equal(ops.gate_update(xs, None, zs, 0.25, training=False), xs + xs * torch.sigmoid(zs))
+
+
 @pytest.mark.parametrize("M,d,dff", [(16 * 64 * 64, 64, 128), (4 * 64 * 64, 256, 512), (256, 1024, 1024), (300, 24, 40)])
 def test_ffn_gate_handover(ops, M, d, dff, default_routes):
     """ops.ffn: the ReLU gate of the first Linear is applied by the second one's input-gradient call (in the product's
