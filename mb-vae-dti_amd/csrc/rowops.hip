@@ -381,24 +381,41 @@ __global__ __launch_bounds__(1024) void pool_pairs_fwd_kernel(const float* __res
   const int L = n * n;
   float cnt = 0.f, skipped = 0.f;
   int i = grp / n, j = grp % n;
-  for (int l = grp; l < L; l += GROUPS) {
-    if (mk[i] && mk[j]) {
-      const float4 v = ld4(x + ((int64_t)b * L + l) * D + c);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      cnt += 1.f;
-      const float inv = 1.f / cnt;
+  // Four pairs per trip: their loads are issued together (the running moments make the updates one dependent chain, so a
+  // lane with one load in flight waits a full memory latency per pair), then consumed in pair order as before.
+  constexpr int U = 4;
+  for (int l = grp; l < L; l += GROUPS * U) {
+    float4 v[U];
+    int kind[U];                                   // 0: past the end, 1: valid pair, 2: padding pair
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float d = vv[q] - mo[q].mean;
-        mo[q].mean += d * inv;
-        mo[q].m2 += d * (vv[q] - mo[q].mean);
-        mn[q] = fminf(mn[q], vv[q]); mx[q] = fmaxf(mx[q], vv[q]);
+    for (int u = 0; u < U; ++u) {
+      const int lu = l + u * GROUPS;
+      kind[u] = 0;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lu < L) {
+        kind[u] = (mk[i] && mk[j]) ? 1 : 2;
+        if (kind[u] == 1) v[u] = ld4(x + ((int64_t)b * L + lu) * D + c);
+        j += GROUPS;
+        while (j >= n) { j -= n; ++i; }
       }
-    } else {
-      skipped += 1.f;
     }
-    j += GROUPS;
-    while (j >= n) { j -= n; ++i; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kind[u] == 1) {
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        cnt += 1.f;
+        const float inv = 1.f / cnt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = vv[q] - mo[q].mean;
+          mo[q].mean += d * inv;
+          mo[q].m2 += d * (vv[q] - mo[q].mean);
+          mn[q] = fminf(mn[q], vv[q]); mx[q] = fmaxf(mx[q], vv[q]);
+        }
+      } else if (kind[u] == 2) {
+        skipped += 1.f;
+      }
+    }
   }
   const int64_t nv = nvalid[0];
   if (skipped > 0.f && nv < M) {
