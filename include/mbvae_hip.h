@@ -75,8 +75,10 @@ int mbvae_linear_bwd_input(const float* dy, int64_t lddy, const float* w, float*
                            mbvae_stream_t stream);
 /* dx[M,K] = pro(dy)[M,N] @ w[N,K] + addend[M,K]: the input gradient of a Linear layer whose input also feeds other
  * consumers (graph_transformer.py:114-146, 187-267: the edge tensor E goes to e_mul/e_add, Etoy and the residual),
- * with the other consumers' gradient folded in instead of a separate accumulation pass.  Only [bs*n*n, d] shapes
- * (M >= 32768, M % 32 == 0, N % 64 == 0, K % 64 == 0, K*N <= 32768); MBVAE_EUNSUPPORTED otherwise. */
+ * with the other consumers' gradient folded in instead of a separate accumulation pass.  The [bs*n*n, d] shapes
+ * (M >= 32768, M % 32 == 0, N % 64 == 0, K % 64 == 0, K*N <= 32768) add it inside the wave-autonomous kernel, any other
+ * shape of at least 1024 rows (the node tensor X, which goes to q|k|v, Xtoy and the residual) in the tiled kernel's
+ * epilogue; MBVAE_EUNSUPPORTED below 1024 rows (the caller then adds it in a separate pass). */
 int mbvae_linear_bwd_input_add(const float* dy, int64_t lddy, const float* w, const float* addend, float* dx,
                                int64_t lddx, int64_t M, int64_t K, int64_t N, const float* gate, float gate_scale,
                                const uint8_t* mask, int mask_mode, int n_nodes, mbvae_stream_t stream);

@@ -48,7 +48,8 @@ struct GemmArgs {
   float* colsum;
   // split-K
   int k_per_split; float* partial; float* partial_colsum;
-  // optional addend with C's layout (C = epi(...) + addend): only the wave-autonomous tall-skinny kernel applies it
+  // optional addend with C's layout (C = epi(...) + addend): the wave-autonomous tall-skinny kernel and the tiled kernel
+  // (epilogue, or the split reduction's) apply it
   const float* addend;
   // optional output gate with C's layout (C = c_gate > 0 ? epi(...) * c_gate_scale : 0): the ReLU / dropout gate of the
   // layer BELOW applied where this layer's input gradient is produced; only the wave-autonomous tall-skinny kernel
@@ -79,6 +80,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int r
   if (g.drop_p > 0.f) v *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
   v = keep_row != 0.f ? v : 0.f;      // a select: a masked row may hold non-finite values
   if (g.accumulate) v += g.C[(int64_t)row * g.ldc + col];
+  if (g.addend) v += g.addend[(int64_t)row * g.ldc + col];
   return v;
 }
 
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           if (g.drop_p > 0.f) o *= mbvae_drop_scale(g.drop_p, g.seed, (uint64_t)row * (uint64_t)g.ldc + col);
           o = keep[v] != 0.f ? o : 0.f;
           if (g.accumulate) o += g.C[(int64_t)row * g.ldc + col];
+          if (g.addend) o += g.addend[(int64_t)row * g.ldc + col];
           g.C[(int64_t)row * g.ldc + col] = o;
         }
       }
@@ -2265,7 +2268,9 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   if (A_KC) {
     const int st = tsgemm_try<B_KC>(g, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;
-    if (g.addend) return MBVAE_EUNSUPPORTED;       // the caller adds it with a separate pass
+    // An addend outside the tall-skinny shapes: the tiled kernel adds it in its epilogue (or in the split reduction's).
+    // Outputs of few rows stay with the small-output kernel, which has no addend: the caller adds it in a separate pass.
+    if (g.addend && g.M < 1024) return MBVAE_EUNSUPPORTED;
   } else if (!B_KC) {
     const int st = tswgrad_try(g, workspace, ws_bytes, stream);
     if (st != MBVAE_EUNSUPPORTED) return st;

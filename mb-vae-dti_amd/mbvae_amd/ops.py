@@ -11,6 +11,8 @@ import torch
 from . import _lib
 
 MASK_NONE, MASK_NODE, MASK_EDGE = 0, 1, 2
+# A/B aid: below the edge-tensor shapes, add a residual gradient in a separate pass instead of the tiled product's epilogue
+_NO_GENERIC_ADDEND = os.environ.get("MBVAE_NO_GENERIC_ADDEND", "0") not in ("", "0")
 
 # Opt-in reduced-precision STORAGE of the training step's largest activations (the edge block's [bs,n,n,2dx]
 # projection output and its gradient, the attention output P [bs,n,n,dx] and its gradient): bf16 in memory, fp32
@@ -187,6 +189,7 @@ class _Linear(torch.autograd.Function):
             folded = False
             if dres is not None:
                 dres = _f32c(dres, "dres").reshape(M, K)
+            if dres is not None and (M >= 32768 or not _NO_GENERIC_ADDEND):
                 folded = _lib.call("mbvae_linear_bwd_input_add", dy2.data_ptr(), N, w.data_ptr(), dres.data_ptr(), dx.data_ptr(), K,
                                    M, K, N, _ptr(gate), gscale, _ptr(m8), mm, n_nodes, _stream(), tag=(M, K, N),
                                    allow_unsupported=True)
