@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const float* __restrict
 
 // Backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma;  dx = dz;  dr = dz * dropscale.
 // Per-block partial sums of dgamma/dbeta go to part[blockIdx.x][2][D] (summed by colsum_partials_kernel).
+#ifndef LN_BWD_UNR
+#define LN_BWD_UNR 2      // rows per trip of the narrow-row form (tuning macro; 3 and 4 measured the same / slightly slower)
+#endif
 template <int LPR, int VPL>
 __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean_in,
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_res_bwd_kernel(const float* __restrict
   }
   // Narrow rows (one 16-byte word per lane) take two rows per trip, every load of both issued before the first use:
   // with two or three streams of 16 bytes per lane the kernel is otherwise short of bytes in flight.
-  constexpr int UNR = VPL == 1 ? 2 : 1;
+  constexpr int UNR = VPL == 1 ? LN_BWD_UNR : 1;
   const int64_t stride = (int64_t)gridDim.x * GROUPS;
   for (int64_t row0 = (int64_t)blockIdx.x * GROUPS + grp; row0 < rows; row0 += stride * UNR) {
     float4 zz[UNR][VPL], dd[UNR][VPL];
