@@ -2256,6 +2256,9 @@ static int thin_try(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t s
   return mbvae_launch_status();
 }
 
+#ifndef GEMM_MID_SPLIT
+#define GEMM_MID_SPLIT 1     // tuning macro: 0 keeps products of 256..767 tiles unsplit
+#endif
 template <bool A_KC, bool B_KC>
 static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return MBVAE_EINVAL;
@@ -2293,8 +2296,11 @@ static int gemm_dispatch(GemmArgs g, void* workspace, int64_t ws_bytes, hipStrea
   if (tiles > 0x7fffffff) return MBVAE_EUNSUPPORTED;
   // split the reduction until ~2 blocks per CU are in flight
   int splits = 1;
-  if (tiles < 256 && g.K >= 256) {
-    splits = (int)std::min<int64_t>(512 / tiles, g.K / 128);
+  // (second case: one to three workgroups per CU with a long reduction each - the global-feature products of a sampling
+  //  chunk, ~1250 rows x 1024 - are bound by the latency of their 32+ dependent k-steps: more, shorter workgroups)
+  const bool mid = GEMM_MID_SPLIT && tiles >= 256 && tiles < 768 && g.K >= 512;
+  if ((tiles < 256 && g.K >= 256) || mid) {
+    splits = mid ? (int)std::min<int64_t>((1024 + tiles - 1) / tiles, g.K / 256) : (int)std::min<int64_t>(512 / tiles, g.K / 128);
     const int64_t per = ((int64_t)g.M * g.N + g.M) * 4;
     if (workspace == nullptr || ws_bytes < per * 2) splits = 1;
     else splits = (int)std::min<int64_t>(splits, ws_bytes / per);

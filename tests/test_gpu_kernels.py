@@ -100,6 +100,8 @@ def test_linear_fwd_bwd(ops, M, K, N, act, mode):
 @pytest.mark.parametrize("M,K,N,act,mode", [
     (16384, 256, 256, 1, "node"), (16384, 256, 256, 0, "none"), (8192, 256, 768, 0, "node"), (4096, 128, 192, 1, "none"),
     (512, 1024, 1024, 1, "none"), (1024, 2048, 128, 0, "none"), (640, 96, 64, 0, "node"),
+    # a sampling chunk's global-feature product: 320 tiles of 64x64 (ragged last row tile), reduction split in three
+    (1250, 1024, 1024, 1, "none"),
 ])
 def test_generic_gemm_on_the_bf16_pipeline_matches_the_fp32_route(ops, M, K, N, act, mode):
     """Whole aligned tiles of the generic LDS-tiled kernel run on the bf16 matrix pipeline (operand octets split once,

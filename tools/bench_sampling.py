@@ -23,6 +23,7 @@ ap.add_argument("--fixed-n", type=int, default=0, help="all molecules of this si
 ap.add_argument("--buckets", type=int, default=1, help="size-sorted sub-batches (sample_batch(size_buckets=...))")
 ap.add_argument("--sort", action="store_true", help="with one bucket: still lay the molecules out by size")
 ap.add_argument("--graph", action="store_true", help="capture one reverse step in a HIP graph and replay it")
+ap.add_argument("--kernel-table", action="store_true", help="after the timed steps: 5 more with every library call bracketed by HIP events, per (entry point, shape) to stderr")
 a = ap.parse_args()
 # molecules are independent: every rank samples its own chunk (generator seeded seed + rank), no collective in the loop
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -102,6 +103,16 @@ with torch.no_grad():
             run(a.steps, T - 1 - a.warmup)
         torch.cuda.synchronize()
         total_ms += 1000 * (time.perf_counter() - t0) / a.steps
+        if a.kernel_table and not a.graph and rank == 0:
+            from mbvae_amd import _lib
+            _lib.PROFILE = {}
+            run(5, T - 1 - a.warmup - a.steps)
+            torch.cuda.synchronize()
+            prof, _lib.PROFILE = _lib.PROFILE, None
+            rows = sorted(((sum(x.elapsed_time(y) for x, y in evs), len(evs), name, tag) for (name, tag), evs in prof.items()), reverse=True)
+            print(f"library calls: {sum(r[0] for r in rows) / 5:.2f} ms per step", file=sys.stderr)
+            for ms_, calls, name, tag in rows[:30]:
+                print(f"  {ms_ / 5:7.3f} ms/step {calls / 5:6.1f} calls  avg {1e3 * ms_ / calls:7.1f} us  {name} {tag}", file=sys.stderr)
 ms = total_ms                     # one reverse step of the whole chunk (all buckets)
 if world > 1:
     worst = torch.tensor([ms], device=dev)
