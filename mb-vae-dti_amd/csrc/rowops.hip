@@ -366,17 +366,23 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(const float* __restrict__ 
 // rows enter as `count x the constant row`, merged with Chan's formula (exact arithmetic, different rounding than
 // walking over them).  The constant row is x[row_idx[32 * ceil(nvalid / 32)]], the first padding row of the packed
 // row order; the padding rows themselves need not have been written.  No arg-min / arg-max output (forward only).
-// One 1024-thread block per graph; D = 64.
-__global__ __launch_bounds__(1024) void pool_pairs_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
+// One NT-thread block per graph; D = 64.  NT = 512: with 40 KB of LDS several graphs share a CU, so one block's load phase
+// runs under another's merge tree (1024 threads and 80 KB meant one graph per CU at a time, phases in series: 146 us per
+// call on 1250 molecules; 512: 102 us, 256: 110 us, 128: 196 us).
+#ifndef POOL_PAIRS_NT
+#define POOL_PAIRS_NT 512     // threads per graph (tuning macro)
+#endif
+template <int NT>
+__global__ __launch_bounds__(NT) void pool_pairs_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                               const uint8_t* __restrict__ mask,
                                                               const int32_t* __restrict__ row_idx,
                                                               const int32_t* __restrict__ nvalid, int n, int64_t M) {
-  extern __shared__ float sm[];                    // [64 groups][16 lanes][4][5]
+  extern __shared__ float sm[];                    // [NT / 16 groups][16 lanes][4][5]
   __shared__ uint8_t mk[1024];
-  constexpr int D = 64, LPR = 16, GROUPS = 64;
+  constexpr int D = 64, LPR = 16, GROUPS = NT / LPR;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int b = blockIdx.x, c = sub * 4;
-  for (int t = threadIdx.x; t < n; t += 1024) mk[t] = mask[(int64_t)b * n + t];
+  for (int t = threadIdx.x; t < n; t += NT) mk[t] = mask[(int64_t)b * n + t];
   __syncthreads();
   Moments mo[4]; float mn[4], mx[4];
 #pragma unroll
@@ -866,9 +872,10 @@ int mbvae_pool_stats_pairs_fwd(const float* x, float* stats, const uint8_t* mask
   (void)hipGetLastError();  // drop stale (non-sticky) errors left by other runtime users
   if (!x || !stats || !mask || !row_idx || !nvalid || bs <= 0 || n <= 0) return MBVAE_EINVAL;
   if (D != 64 || n > 1024 || bs > 0x7fffffff || bs * n * n > 0x7fffffff) return MBVAE_EUNSUPPORTED;
-  const size_t smem = (size_t)1024 * 4 * 5 * sizeof(float);
-  if (!MBVAE_ALLOW_BIG_LDS(pool_pairs_fwd_kernel)) return MBVAE_ELAUNCH;
-  hipLaunchKernelGGL(pool_pairs_fwd_kernel, dim3((unsigned)bs), dim3(1024), smem, stream, x, stats, mask, row_idx, nvalid,
+  constexpr int NT = POOL_PAIRS_NT;
+  const size_t smem = (size_t)NT * 4 * 5 * sizeof(float);
+  if (!MBVAE_ALLOW_BIG_LDS(pool_pairs_fwd_kernel<NT>)) return MBVAE_ELAUNCH;
+  hipLaunchKernelGGL(pool_pairs_fwd_kernel<NT>, dim3((unsigned)bs), dim3(NT), smem, stream, x, stats, mask, row_idx, nvalid,
                      (int)n, bs * n * n);
   return mbvae_launch_status();
 }
