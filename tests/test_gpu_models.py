@@ -72,6 +72,40 @@ def test_blocks_and_heads_golden(name):
         assert_close(t.grad, g[f"{name}_din{i}"], what=f"{name} input grad {i}")
 
 
+@pytest.mark.parametrize("name", ["trfenc", "fusion"])
+def test_gated_blocks_in_training_mode(name):
+    """TransformerEncoder and CrossAttentionFusion with their modules in training mode (the sigmoid gates then go through
+    the keep-mask form of the gate kernels): with every dropout probability at zero the outputs and gradients are those of
+    evaluation mode bit for bit; with dropout on, the same torch seed gives the same bits twice, and the result differs
+    from evaluation mode."""
+    g = load_golden("encoders")
+    mod, fn, ins = _block_cases(g)[name]
+    mod.load_state_dict(g["sd_" + name], strict=True)
+    mod = mod.cuda()
+
+    def run(train, p, seed=0):
+        for m in mod.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = p
+        mod.train(train)
+        for q in mod.parameters():
+            q.grad = None
+        torch.manual_seed(seed)
+        leaves = [t.clone().cuda().requires_grad_(True) for t in ins]
+        out = fn(mod, leaves)[0]
+        (out * g[f"{name}_cot0"].cuda()).sum().backward()
+        return [out.detach()] + [t.grad for t in leaves] + [q.grad.clone() for q in mod.parameters()]
+
+    ev = run(False, 0.1)
+    assert_close(ev[0], g[f"{name}_out"], what=f"{name} evaluation output")
+    tr0 = run(True, 0.0)
+    assert all(torch.equal(a, b) for a, b in zip(ev, tr0)), "training mode without dropout differs from evaluation mode"
+    a, b = run(True, 0.3, seed=5), run(True, 0.3, seed=5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "same seed, different bits"
+    assert not torch.equal(a[0], ev[0])
+    assert all(torch.isfinite(t).all() for t in a)
+
+
 # ------------------------------------------------------------------------------------------------ model variants
 COMMON = dict(learning_rate=1e-3, weight_decay=1e-4, scheduler="const", embedding_dim=32, hidden_dim=16, factor=4, n_layers=2,
               activation="relu", dropout=0.1, bias=True)
