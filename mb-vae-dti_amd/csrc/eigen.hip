@@ -103,8 +103,8 @@ __global__ __launch_bounds__(EIG_NT) void sym_eig_jacobi_kernel(const float* __r
     __syncthreads();
     // Converged, or at the rounding floor: in fp32 the off-diagonal mass stalls at 1e-14 .. 2e-14 of the total (the square of
     // the unit round-off), so a fixed bound there is met by some matrices and never by others; a sweep that no longer
-    // halves an already tiny mass ends the iteration.
-    if (off2 <= 1e-14f * total2 || off2 == 0.f || (off2 <= 1e-10f * total2 && off2 >= 0.5f * prev_off2)) break;
+    // halves a mass already below 1e-12 of the total (ten times the floor's upper end) ends the iteration.
+    if (off2 <= 1e-14f * total2 || off2 == 0.f || (off2 <= 1e-12f * total2 && off2 >= 0.5f * prev_off2)) break;
     prev_off2 = off2;
 
     for (int r = 0; r < m - 1; ++r) {
