@@ -1,6 +1,5 @@
 # A/B on one box: the residual gradient of the node feed-forward block folded into the tiled product's epilogue (default)
-# against a separate sum (MBVAE_NO_GENERIC_ADDEND=1).  (The run recorded in DESIGN.md also had X's q|k|v / Xtoy / residual
-# fan-out as one autograd node, behind a switch that was removed with it.)
+# against a separate sum (MBVAE_NO_GENERIC_ADDEND=1).
 set -e
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
 for i in 1 2; do
